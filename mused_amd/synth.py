@@ -1,0 +1,72 @@
+"""Seeded synthetic feature streams.
+
+NumPy only; used by bench.py, the tests and the golden-fixture generator so
+that inputs are regenerated from a seed instead of being stored.
+
+  gauss : iid N(0, 1) rows (the BASELINE.json wording).
+  blob  : `n_centres` centres ~ N(0, sep^2 I_d); label uniform; row = centre +
+          N(0, I).  Labels give `n_clusters` per window (main.py:41).
+  fd    : A = S D U + N / zeta, the Frequent-Directions paper generator implied
+          by the file name at data_loader.py:191 (m = signal rank, zeta = SNR).
+
+All streams are float32-valued (storage dtype of the device path); callers
+promote to float64 where the reference does.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+
+def gauss_stream(n: int, d: int, seed: int = 0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    # structure-less stream: labels only fix n_clusters per window (main.py:41)
+    labels = np.random.default_rng(seed + 1000003).integers(0, 4, size=n).astype(np.int64)
+    return X, labels
+
+
+def blob_stream(n: int, d: int, seed: int = 0, n_centres: int = 8, sep: float = 2.0):
+    rng = np.random.default_rng(seed)
+    centres = (sep * rng.standard_normal((n_centres, d))).astype(np.float32)
+    labels = rng.integers(0, n_centres, size=n)
+    X = centres[labels] + rng.standard_normal((n, d), dtype=np.float32)
+    return X.astype(np.float32), labels.astype(np.int64)
+
+
+def fd_stream(n: int, d: int, seed: int = 0, m: int = 10, zeta: float = 10.0):
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((n, m))
+    D = np.diag(1.0 - np.arange(m) / m)
+    U, _ = np.linalg.qr(rng.standard_normal((d, m)))
+    A = S @ D @ U.T + rng.standard_normal((n, d)) / zeta
+    return A.astype(np.float32), np.zeros(n, dtype=np.int64)
+
+
+def two_modality_blob_stream(n: int, d_each: int, seed: int = 0, n_centres: int = 8, sep: float = 2.0):
+    """BASELINE config 4: two d_each-dim modalities sharing one label sequence."""
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, n_centres, size=n)
+    mods = []
+    for _ in range(2):
+        centres = (sep * rng.standard_normal((n_centres, d_each))).astype(np.float32)
+        mods.append((centres[labels] + rng.standard_normal((n, d_each), dtype=np.float32)).astype(np.float32))
+    return mods, labels.astype(np.int64)
+
+
+STREAMS = {"gauss": gauss_stream, "blob": blob_stream, "fd": fd_stream}
+
+
+def make_stream(kind: str, n: int, d: int, seed: int = 0, **kw):
+    return STREAMS[kind](n, d, seed, **kw)
+
+
+def array_digest(a: np.ndarray) -> str:
+    """SHA-256 of dtype, shape and C-order bytes (used to pin regenerated inputs)."""
+    a = np.ascontiguousarray(a)
+    h = hashlib.sha256()
+    h.update(str(a.dtype).encode())
+    h.update(str(a.shape).encode())
+    h.update(a.tobytes())
+    return h.hexdigest()

@@ -1,0 +1,74 @@
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: several seconds of CPU work")
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"golden fixture {name}.npz not generated")
+    return np.load(path, allow_pickle=False)
+
+
+def nbr_hash(A) -> str:
+    """Same digest as tests/golden/make_golden.py: rows of sorted neighbour columns."""
+    A = np.asarray(A)
+    h = hashlib.sha256()
+    for i in range(A.shape[0]):
+        cols = np.flatnonzero(A[i]).astype(np.int32)
+        h.update(np.int32(i).tobytes())
+        h.update(np.int32(len(cols)).tobytes())
+        h.update(cols.tobytes())
+    return h.hexdigest()
+
+
+def nbr_hash_from_lists(rows) -> str:
+    """Digest from per-row sorted int32 neighbour arrays (no dense matrix)."""
+    h = hashlib.sha256()
+    for i, cols in enumerate(rows):
+        cols = np.asarray(cols, dtype=np.int32)
+        h.update(np.int32(i).tobytes())
+        h.update(np.int32(len(cols)).tobytes())
+        h.update(cols.tobytes())
+    return h.hexdigest()
+
+
+def regen_inputs(g):
+    """Regenerate the seeded inputs of a golden case and check their digest."""
+    from mused_amd import synth
+
+    n, d, W, ell, k, seed = (int(x) for x in g["meta"])
+    kind = str(g["kind"])
+    if kind == "blob2":
+        mods, labels = synth.two_modality_blob_stream(n, d, seed, n_centres=4)
+    elif kind == "blob":
+        nc = 8 if d >= 256 else 4
+        X, labels = synth.blob_stream(n, d, seed, n_centres=nc, sep=2.0)
+        mods = [X]
+    else:
+        X, labels = synth.make_stream(kind, n, d, seed)
+        mods = [X]
+    digests = [synth.array_digest(m) for m in mods]
+    assert digests == [str(x) for x in g["input_digest"]], "regenerated inputs differ from the golden run's"
+    return mods, labels, (n, d, W, ell, k, seed)
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    import torch
+
+    return torch.cuda.is_available()

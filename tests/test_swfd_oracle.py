@@ -1,0 +1,110 @@
+"""Property tests for the SWFD specification (oracle/swfd_oracle.py).
+
+There is no reference source for SeqBasedSWFD in the container (un-vendored
+submodule) -> parity unpinned; these are the size-independent properties the
+literature guarantees for a sliding-window FD sketch, plus the call-surface
+contract read from main.py:62-76."""
+import numpy as np
+import pytest
+
+from mused_amd import synth
+from oracle.swfd_oracle import SeqBasedSWFD
+
+C_BOUND = 1.0  # ||A_W^T A_W - B^T B||_2 <= C_BOUND * ||A_W||_F^2 / ell   (measured max 0.54)
+
+
+def cov_err(X, t, N, B):
+    W = X[max(0, t - N) : t].astype(np.float64)
+    E = W.T @ W - B.T @ B
+    return np.linalg.norm(E, 2), np.linalg.norm(W) ** 2
+
+
+@pytest.mark.parametrize("kind", ["gauss", "blob", "fd"])
+def test_covariance_error_bound(kind):
+    N, ell, d = 400, 8, 40
+    X, _ = synth.make_stream(kind, 4 * N + 37, d, 3)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    sk = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
+    for t in range(1, len(X) + 1):
+        sk.fit(X[t - 1 : t])
+        if t % 137 == 0 or t % N == 0:
+            B, sigma, lvl, delta = sk.get()
+            assert B.shape == (ell, d) and B.dtype == np.float64
+            err, f2 = cov_err(X, t, N, B)
+            assert err <= C_BOUND * f2 / ell + 1e-9
+            np.testing.assert_allclose(sigma, np.linalg.norm(B, axis=1))
+            # rows of the sketch are mutually orthogonal, sorted by decreasing norm
+            G = B @ B.T
+            off = G - np.diag(np.diag(G))
+            assert np.abs(off).max() <= 1e-8 * max(G.max(), 1.0)
+            assert np.all(np.diff(sigma) <= 1e-9 * sigma[0])
+            assert 0 <= lvl < sk.L
+
+
+def test_expiry_forgets_old_direction():
+    """A heavy direction that left the window must leave the sketch."""
+    N, ell, d = 300, 6, 24
+    rng = np.random.default_rng(0)
+    heavy = np.zeros((N, d))
+    heavy[:, 0] = 30.0 * (1 + 0.1 * rng.standard_normal(N))
+    tail = rng.standard_normal((2 * N + 11, d))
+    X = np.vstack([heavy, tail])
+    R = float((X**2).sum(1).max())
+    sk = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
+    sk.fit(X[:N])
+    B0 = sk.get()[0]
+    assert (B0[:, 0] ** 2).sum() > 0.5 * (heavy[:, 0] ** 2).sum()
+    sk.fit(X[N:])
+    B, _, _, _ = sk.get()
+    err, f2 = cov_err(X, len(X), N, B)
+    assert err <= C_BOUND * f2 / ell
+    # energy along e_0 is now at the level of the Gaussian tail, not 900 * N
+    assert (B[:, 0] ** 2).sum() < 5 * N
+
+
+def test_batching_invariance_and_dtypes():
+    N, ell, d = 128, 4, 16
+    X, _ = synth.gauss_stream(3 * N + 5, d, 1)
+    Xi = np.rint(3 * X).astype(np.int64)  # fused matrix is int64 when M >= 2 (matrix_operations.py:138)
+    R = float((Xi.astype(np.float64) ** 2).sum(1).max())
+    a = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
+    for r in range(len(Xi)):
+        a.fit(Xi[r, :].reshape(1, -1))  # main.py:66-67 call pattern
+    b = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
+    b.fit(Xi[:50])
+    b.fit(Xi[50:51])
+    b.fit(Xi[51:])
+    Ba, sa, la, da = a.get()
+    Bb, sb, lb, db = b.get()
+    assert la == lb and da == db
+    assert np.array_equal(Ba, Bb) and np.array_equal(sa, sb)
+
+
+def test_call_surface():
+    sk = SeqBasedSWFD(N=8, R=1.0, d=8, sketch_dim=2)  # main.py:62 keywords; main.py:318-324 demo sizes
+    assert sk.L == 1
+    out = sk.get()  # query before any row
+    assert len(out) == 4 and out[0].shape == (2, 8) and not out[0].any()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        assert sk.fit(rng.integers(0, 2, size=(1, 8))) is sk
+    B = sk.get()[0]
+    assert B.shape == (2, 8)
+    assert SeqBasedSWFD(N=10, R=49.0, d=10, sketch_dim=3).L == 7  # R = 49 -> 7 levels
+    with pytest.raises(ValueError):
+        sk.fit(np.zeros((1, 7)))
+    with pytest.raises(ValueError):
+        SeqBasedSWFD(N=0, R=1.0, d=8, sketch_dim=2)
+
+
+def test_mused_wiring_transposed_sketch():
+    """main.py:62-76: d = window size; the caller transposes get()[0] to (W, m)."""
+    W, ell = 64, 5
+    rng = np.random.default_rng(2)
+    fused = (rng.random((W, W)) < 0.1).astype(np.float64)
+    R = float(np.max(np.linalg.norm(fused, axis=1) ** 2))
+    sk = SeqBasedSWFD(N=W, R=R, d=W, sketch_dim=ell)
+    for r in range(W):
+        sk.fit(fused[r, :].reshape(1, -1))
+    red = sk.get()[0]
+    assert red.shape[0] != W and red.T.shape == (W, ell)
