@@ -1,0 +1,132 @@
+/* libmused_hip -- C ABI of the MI355X (gfx950) hot path of mused.
+ *
+ * The reference (kelaendi/mused) has no FFI: its hot path sits behind two Python import lines,
+ *   from matrix_operations import create_adjacency_matrix, fuse_matrices, perform_svd_reduction, ...   (main.py:5)
+ *   from swfd import SeqBasedSWFD                                                                     (main.py:10)
+ * This header is the drop-in boundary underneath those names: plain pointers and sizes, no torch
+ * types.  Every pointer is a DEVICE pointer unless stated otherwise; `stream` is a hipStream_t;
+ * outputs are caller-allocated; the library owns only the opaque handles.  Every function returns
+ * 0 on success or a negative code (MUSED_ERR_*), the message is in mused_last_error().
+ * No function synchronises with the host unless its comment says so.
+ *
+ * The Python host side that mirrors the reference's call surface on top of this ABI is
+ * mused_amd/matrix_operations.py and mused_amd/swfd.py; INTEGRATION.md shows the binding.
+ */
+#ifndef MUSED_HIP_H
+#define MUSED_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUSED_OK 0
+#define MUSED_ERR_ARG -1
+#define MUSED_ERR_HIP -2
+#define MUSED_ERR_STATE -3
+#define MUSED_ERR_UNSUPPORTED -4
+
+/* element types of caller-provided row data */
+#define MUSED_F32 0
+#define MUSED_F64 1
+#define MUSED_I64 2
+
+/* metric of the pairwise score */
+#define MUSED_METRIC_L2 0     /* squared Euclidean, matrix_operations.py:112-119 (sklearn NearestNeighbors) */
+#define MUSED_METRIC_COSINE 1 /* negated cosine similarity, matrix_operations.py:106-108 */
+
+const char* mused_last_error(void);
+int mused_version(void);
+/* async device-to-device copy on `stream` */
+int mused_memcpy_d2d(void* dst, const void* src, long bytes, void* stream);
+
+/* ---- a1 / a2: similarity -> k nearest rows ------------------------------------------------- */
+
+/* out[i] = sum_j X[i][j]^2 (fp64).  Row norms of main.py:61 and of sklearn's Euclidean / cosine kernels. */
+int mused_row_sq_norms(const void* X, int dtype, long n, int d, long ld, double* out, void* stream);
+
+/* S (n x n fp64, pitch n): metric L2: max(0, |x_i|^2 - 2 x_i.x_j + |x_j|^2); COSINE: -(x_i.x_j)/(|x_i||x_j|)
+ * (zero norms -> 1).  norms: n-double workspace.  fp64 MFMA GEMM with fused epilogue. */
+int mused_pairwise_scores(const void* X, int dtype, long n, int d, long ld, int metric, double* norms, double* S,
+                          void* stream);
+
+/* Per row of S the k smallest entries, ties to the smaller column.  out_idx (n x k int32, ascending
+ * columns) and out_mask (n x mask_words uint64 bitmask, the row's own column cleared --
+ * matrix_operations.py:128) may each be NULL. */
+int mused_select_k_smallest(const double* S, long ld, int n, int k, int* out_idx, unsigned long long* out_mask,
+                            int mask_words, void* stream);
+
+/* Replaces NearestNeighbors(n_neighbors=k).fit(X).kneighbors(X) + the adjacency write loop
+ * (matrix_operations.py:118-130), and cosine_similarity + argsort[:, :k] (:106-108), for dense rows.
+ * ws_scores: n*n doubles, ws_norms: n doubles. */
+int mused_knn_topk(const void* X, int dtype, long n, int d, long ld, int k, int metric, double* ws_scores,
+                   double* ws_norms, int* out_idx, unsigned long long* out_mask, int mask_words, void* stream);
+
+/* ---- a3 / a4: adjacency bitmasks -------------------------------------------------------------
+ * An adjacency is n rows x words uint64 (words >= ceil(n/64)); bit j of row i <=> A[i][j] = 1. */
+
+/* Replaces fuse_matrices (matrix_operations.py:134-141).  `masks`: HOST array of M device pointers. */
+int mused_adj_fuse(const unsigned long long* const* masks, int M, int n, int words, unsigned long long* out,
+                   void* stream);
+/* deg[n], rowptr[n+1] (exclusive scan), stats = {max degree, nnz}; max degree = R of main.py:61. */
+int mused_adj_degrees(const unsigned long long* mask, int n, int words, int* deg, int* rowptr, int* stats,
+                      void* stream);
+int mused_adj_csr_fill(const unsigned long long* mask, int n, int words, const int* rowptr, int* colidx,
+                       void* stream);
+int mused_adj_transpose(const unsigned long long* mask, int n, int words, unsigned long long* out, void* stream);
+/* dense n x n export (MUSED_F64: one modality, matrix_operations.py:135; MUSED_I64: fused, :138) */
+int mused_adj_to_dense(const unsigned long long* mask, int n, int words, int dtype, void* out, void* stream);
+/* dense import (nonzero -> edge); *nonbinary (device int, pre-zeroed) set if an entry is not 0/1 */
+int mused_adj_from_dense(const void* dense, int dtype, int n, long ld, int words, unsigned long long* mask,
+                         int* nonbinary, void* stream);
+
+/* ---- a8: randomized truncated SVD (perform_svd_reduction, matrix_operations.py:143-147) ------ */
+
+int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** handle);
+int mused_rsvd_destroy(void* handle);
+/* buffer the fused adjacency bitmask (pitch ceil(n/64)) must be written to before mused_rsvd_reduce */
+unsigned long long* mused_rsvd_mask_buffer(void* handle);
+/* Q0 = np.random.RandomState(seed).normal(size=(n, r)) uploaded by the host (sklearn:utils/extmath.py:297) */
+int mused_rsvd_set_q0(void* handle, const double* Q0, int n, int r, void* stream);
+/* out_embed (n x n_comp) = X @ Vt.T, out_sigma (n_comp) = singular_values_, out_components (n x n_comp,
+ * may be NULL) = Vt.T after svd_flip. */
+int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double* out_embed, double* out_sigma,
+                      double* out_components, void* stream);
+/* BLOCKING: flags_out[0] != 0 -> more than nnz_cap edges; stats_out = {max out-deg, nnz, max in-deg, nnz} (HOST) */
+int mused_rsvd_status(void* handle, int* flags_out, int* stats_out, void* stream);
+
+/* building blocks of the eigenstep, exported for unit tests */
+int mused_spmm_binary(const int* rowptr, const int* colidx, int n, const double* Q, long ldq, int r, double* Y,
+                      long ldy, void* stream);
+int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws_f64, void* stream);
+int mused_qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* ws_f64, void* stream);
+/* BLOCKING (creates/destroys its plan): eigen-decomposition of `batch` symmetric n x n matrices, n even */
+int mused_syevj_batched(const double* G, int n, int batch, int sweeps, double* evals, double* V, void* stream);
+int mused_gemm_f64(int a_kc, int b_kc, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                   int M, int N, int K, double alpha, void* stream);
+int mused_gemm_f64_batched(int a_kc, int b_kc, const double* A, long lda, long strideA, const double* B, long ldb,
+                           long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch,
+                           double alpha, void* stream);
+
+/* ---- a5-a7: SeqBasedSWFD (swfd submodule; call sites main.py:62,65-67,70) ---------------------- */
+
+/* SeqBasedSWFD(N=, R=, d=, sketch_dim=) */
+int mused_swfd_create(long N, double R, int d, int sketch_dim, int sweeps, void** handle);
+int mused_swfd_destroy(void* handle);
+int mused_swfd_levels(void* handle);
+/* .fit(row) for n_rows rows at once (any batching gives the same sketch) */
+int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, long ld, void* stream);
+/* .get(): out_sketch (sketch_dim x d), out_sigma (sketch_dim, may be NULL), out_info = {level, delta} (may be NULL) */
+int mused_swfd_query(void* handle, double* out_sketch, double* out_sigma, double* out_info, void* stream);
+int mused_swfd_counters(void* handle, long* rows_seen, int* pending); /* HOST outputs */
+/* state exchange between ranks (one half = the L sketches of kind 0 MAIN / 1 AUX) */
+long mused_swfd_half_bytes(void* handle);
+int mused_swfd_export_half(void* handle, int kind, void* dst, void* stream);
+int mused_swfd_import_half(void* handle, int kind, const void* src, void* stream);
+int mused_swfd_begin_epoch(void* handle, long rows_seen, const void* main_half, void* stream);
+/* BLOCKING unit primitive: one FD rotation of a (2 l x d) buffer in place */
+int mused_fd_rotate(double* buf, int ell, int d, double* sigma_out, int sweeps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSED_HIP_H */

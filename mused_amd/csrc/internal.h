@@ -1,0 +1,49 @@
+// Host-side entry points shared between translation units of libmused_hip.
+#pragma once
+#include "common.h"
+
+namespace mused {
+
+// C[z] = alpha * opA(A[z]) * opB(B[z]); fp64 in / fp64 out, MFMA f64 16x16x4.
+//   a_kc: A stored [M][K] (true) or [K][M] (false);  b_kc: B stored [N][K] (true) or [K][N] (false).
+int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb,
+             long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha,
+             hipStream_t stream);
+
+// Sets the dynamic-LDS attribute of every plain GEMM instantiation (call before stream capture).
+int gemm_f64_prepare_all();
+
+// Split-K variant for short-and-wide products (tiny M x N, long K): partial[z] for
+// z < nsplit (each M x N, ld = N), then reduce with gemm_splitk_reduce.
+int gemm_f64_splitk(bool a_kc, bool b_kc, const double* A, long lda, const double* B, long ldb, double* partial,
+                    int M, int N, int K, int kchunk, int nsplit, hipStream_t stream);
+int gemm_splitk_reduce(const double* partial, int nsplit, long count, double* out, hipStream_t stream);
+
+// Y (n x r) <- P*L (first min(n,r) columns) ; pivstep: n ints, prow: r doubles
+int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, hipStream_t st);
+// Q (n x r) <- economic Householder Q of Y (destroyed); tau: r doubles, wpart: ceil(n/512)*r doubles
+int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart, hipStream_t st);
+// Y = A Q for binary CSR A
+int spmm_binary(const int* rowptr, const int* colidx, int n, const double* Q, long ldq, int r, double* Y, long ldy,
+                hipStream_t stream);
+
+// bitmask -> (deg, rowptr, colidx ascending); stats[0] = max degree, stats[1] = nnz; entries beyond
+// `cap` (if cap > 0) are dropped and *overflow set.
+int adj_csr_from_mask(const unsigned long long* mask, int n, int words, int* deg, int* rowptr, int* colidx,
+                      int* stats, long cap, int* overflow, hipStream_t st);
+int zero_ints(int* p, long n, hipStream_t st);
+int adj_transpose(const unsigned long long* mask, int n, int words, unsigned long long* out, hipStream_t st);
+
+// Batched symmetric eigensolver (cyclic Jacobi, one launch per rotation set).
+struct EigPlan;
+// own_graph: capture the sweep launches into a private hipGraph (set false when the caller
+// captures a larger pipeline that contains this solve).
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out);
+void eig_plan_destroy(EigPlan* p);
+// In: G (batch x n x n, symmetric) is copied into the plan's workspace.  Out: eigenvalues
+// (unsorted, batch x n) and eigenvectors V (batch x n x n, column j <-> eigenvalue j).
+int eig_plan_run(EigPlan* p, const double* G, double* evals, double* V, hipStream_t stream);
+double* eig_plan_input(EigPlan* p);  // (batch x n x n) device buffer the caller may fill directly
+int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t stream, bool allow_graph);
+
+}  // namespace mused

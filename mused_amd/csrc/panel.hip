@@ -1,0 +1,224 @@
+// Tall-skinny panel factorizations used as the power-iteration normalisers of the
+// randomized range finder (sklearn:utils/extmath.py:330-355):
+//   * LU with partial pivoting, returning P*L in place (scipy.linalg.lu(..., permute_l=True))
+//   * Householder QR, returning the economic Q (scipy.linalg.qr(..., mode="economic"))
+// Panels are n x r row-major fp64 with n ~ 10^4, r <= ~300: a few MFLOP of work per column,
+// strictly sequential over columns.  Each column step is a pair/triple of small kernels on
+// the same stream (a kernel boundary is the cheapest grid-wide sync on this chip); the
+// whole sequence is replayed from a hipGraph by the caller.
+//
+// Pivot rule: largest |a_ij| among not-yet-pivoted rows, ties to the smallest ORIGINAL row
+// index (LAPACK's idamax breaks ties by current position, which only differs for exactly
+// equal magnitudes).  Rows are never physically swapped: P*L is what the caller wants.
+#include "internal.h"
+
+namespace mused {
+
+constexpr int PANEL_ROWS_PER_WG = 512;
+
+// ---------------------------------------------------------------- LU -------------
+__global__ __launch_bounds__(1024) void lu_pivot_kernel(double* __restrict__ Y, int n, int r, long ld, int j,
+                                                       int* __restrict__ pivstep, double* __restrict__ prow) {
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ int s_win;
+  double best = -1.0;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    if (pivstep[i] == 0) {
+      const double a = fabs(Y[(long)i * ld + j]);
+      if (a > best || (a == best && i < bi)) { best = a; bi = i; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = s_val[0];
+    int ix = s_idx[0];
+    for (int w = 1; w < 16; ++w)
+      if (s_val[w] > b || (s_val[w] == b && s_idx[w] < ix)) { b = s_val[w]; ix = s_idx[w]; }
+    s_win = ix;
+    pivstep[ix] = j + 1;
+  }
+  __syncthreads();
+  const int win = s_win;
+  for (int c = j + threadIdx.x; c < r; c += 1024) prow[c] = Y[(long)win * ld + c];
+}
+
+// rows not yet pivoted: l = a_ij * (1 / pivot); a_ij <- l; a_ic -= l * prow[c]  (c > j)
+__global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ Y, int n, int r, long ld, int j,
+                                                       const int* __restrict__ pivstep,
+                                                       const double* __restrict__ prow) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int tx = threadIdx.x & 15;
+  if (row >= n || pivstep[row] != 0) return;
+  double* y = Y + (long)row * ld;
+  const double piv = prow[j];
+  const double a = y[j];
+  const double l = (piv != 0.0) ? a * (1.0 / piv) : a;
+  for (int c = j + 1 + tx; c < r; c += 16) y[c] -= l * prow[c];
+  if (tx == 0) y[j] = l;
+}
+
+// pivot rows: unit diagonal at their step, zeros to the right; keep only k = min(n, r) columns
+__global__ void lu_finalize_kernel(double* __restrict__ Y, int n, int k, long ld, const int* __restrict__ pivstep) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int tx = threadIdx.x & 15;
+  if (row >= n) return;
+  const int s = pivstep[row] - 1;
+  if (s < 0) return;
+  double* y = Y + (long)row * ld;
+  for (int c = s + tx; c < k; c += 16) y[c] = (c == s) ? 1.0 : 0.0;
+}
+
+int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, hipStream_t st) {
+  const int k = n < r ? n : r;
+  int zrc = zero_ints(pivstep, n, st);
+  if (zrc) return zrc;
+  for (int j = 0; j < k; ++j) {
+    hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, Y, n, r, ld, j, pivstep, prow);
+    hipLaunchKernelGGL(lu_update_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, Y, n, r, ld, j, pivstep, prow);
+  }
+  hipLaunchKernelGGL(lu_finalize_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, Y, n, k, ld, pivstep);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
+// ---------------------------------------------------------------- QR -------------
+// Column j: Householder vector of Y[j:, j] in place (v_j = 1 implied, stored explicitly),
+// LAPACK dlarfg convention: beta = -sign(alpha) * hypot(alpha, |x|), tau = (beta - alpha)/beta,
+// v = x / (alpha - beta).  tau[j] = 0 when x == 0.
+__global__ __launch_bounds__(1024) void qr_house_kernel(double* __restrict__ Y, int n, long ld, int j,
+                                                       double* __restrict__ tau) {
+  __shared__ double s_sum[16];
+  __shared__ double s_scale;
+  double s = 0.0;
+  for (int i = j + 1 + threadIdx.x; i < n; i += 1024) {
+    const double v = Y[(long)i * ld + j];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double xn2 = 0.0;
+    for (int w = 0; w < 16; ++w) xn2 += s_sum[w];
+    const double alpha = Y[(long)j * ld + j];
+    if (xn2 == 0.0) {
+      tau[j] = 0.0;
+      s_scale = 0.0;
+    } else {
+      const double beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+      tau[j] = (beta - alpha) / beta;
+      s_scale = 1.0 / (alpha - beta);
+    }
+    Y[(long)j * ld + j] = 1.0;
+  }
+  __syncthreads();
+  const double sc = s_scale;
+  for (int i = j + 1 + threadIdx.x; i < n; i += 1024) Y[(long)i * ld + j] *= sc;
+}
+
+// wpart[chunk][c] = sum_{i in chunk, i >= j} v_i * T[i][c]   for c in [c_lo, c_hi)
+// (v = column j of Y; T is Y itself during factorisation, the Q accumulator afterwards)
+__global__ __launch_bounds__(256) void qr_dot_kernel(const double* __restrict__ Y, long ldy, int j,
+                                                    const double* __restrict__ T, long ldt, int n, int c_lo,
+                                                    int c_hi, double* __restrict__ wpart, int wld) {
+  __shared__ double red[4][64];
+  const int chunk = blockIdx.x;
+  const int r0 = max(j, chunk * PANEL_ROWS_PER_WG);
+  const int r1 = min(n, (chunk + 1) * PANEL_ROWS_PER_WG);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int cb = c_lo; cb < c_hi; cb += 64) {
+    const int c = cb + tx;
+    double s = 0.0;
+    if (c < c_hi)
+      for (int i = r0 + ty; i < r1; i += 4) s += Y[(long)i * ldy + j] * T[(long)i * ldt + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < c_hi) wpart[(long)chunk * wld + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    __syncthreads();
+  }
+}
+
+// T[i][c] -= tau_j * v_i * w[c],  w[c] = sum_chunk wpart[chunk][c]   (rows i >= j)
+__global__ __launch_bounds__(256) void qr_update_kernel(const double* __restrict__ Y, long ldy, int j,
+                                                       double* __restrict__ T, long ldt, int n, int c_lo, int c_hi,
+                                                       const double* __restrict__ wpart, int wld, int nchunk,
+                                                       int first_chunk, const double* __restrict__ tau) {
+  extern __shared__ double w[];  // [c_hi - c_lo]
+  const double tj = tau[j];
+  if (tj == 0.0) return;
+  for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+    double s = 0.0;
+    for (int k = first_chunk; k < nchunk; ++k) s += wpart[(long)k * wld + c];
+    w[c - c_lo] = s * tj;
+  }
+  __syncthreads();
+  const int row = j + blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int tx = threadIdx.x & 15;
+  if (row >= n) return;
+  const double v = Y[(long)row * ldy + j];
+  double* t = T + (long)row * ldt;
+  for (int c = c_lo + tx; c < c_hi; c += 16) t[c] -= v * w[c - c_lo];
+}
+
+__global__ void set_identity_kernel(double* __restrict__ Q, int n, int r, long ld) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * r) return;
+  const int row = (int)(gid / r), c = (int)(gid - (long)row * r);
+  Q[(long)row * ld + c] = (row == c) ? 1.0 : 0.0;
+}
+
+int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart,
+                hipStream_t st) {
+  // requires n >= r
+  const int nchunk = cdiv(n, PANEL_ROWS_PER_WG);
+  const int wld = r;
+  for (int j = 0; j < r; ++j) {
+    hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, Y, n, ldy, j, tau);
+    if (j + 1 < r) {
+      const int first = j / PANEL_ROWS_PER_WG;
+      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(256), 0, st, Y, ldy, j, Y, ldy, n, j + 1, r, wpart, wld);
+      hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j - 1), st, Y,
+                         ldy, j, Y, ldy, n, j + 1, r, wpart, wld, nchunk, first, tau);
+    }
+  }
+  hipLaunchKernelGGL(set_identity_kernel, dim3(cdiv((long)n * r, 256)), dim3(256), 0, st, Q, n, r, ldq);
+  for (int j = r - 1; j >= 0; --j) {
+    const int first = j / PANEL_ROWS_PER_WG;
+    hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(256), 0, st, Y, ldy, j, Q, ldq, n, j, r, wpart, wld);
+    hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j), st, Y, ldy, j,
+                       Q, ldq, n, j, r, wpart, wld, nchunk, first, tau);
+  }
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
+}  // namespace mused
+
+using namespace mused;
+
+extern "C" {
+
+// In place: Y (n x r, ld) <- P*L of its LU factorisation with partial pivoting, first
+// min(n, r) columns (scipy.linalg.lu(Y, permute_l=True)[0]).  ws_int: n ints, ws_f64: r doubles.
+int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws_f64, void* stream) {
+  MUSED_REQUIRE(Y && ws_int && ws_f64 && n > 0 && r > 0 && ld >= r, "mused_lu_permute_l: bad arguments");
+  return lu_permute_l(Y, n, r, ld, ws_int, ws_f64, (hipStream_t)stream);
+}
+
+// Q (n x r, ldq) <- economic Householder QR of Y (n x r, ldy; destroyed).  n >= r.
+// ws_f64: r + ceil(n/512)*r doubles.
+int mused_qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* ws_f64, void* stream) {
+  MUSED_REQUIRE(Y && Q && ws_f64 && n >= r && r > 0 && ldy >= r && ldq >= r, "mused_qr_economic: need n >= r");
+  return qr_economic(Y, n, r, ldy, Q, ldq, ws_f64, ws_f64 + r, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+// a8 of SURVEY section 8: the "eigenstep" -- perform_svd_reduction (matrix_operations.py:143-147)
+// = sklearn TruncatedSVD(algorithm="randomized", n_iter=5, n_oversamples=10,
+// power_iteration_normalizer="auto" -> LU).fit_transform on the fused 0/1 adjacency:
+//
+//   Q <- Q0 (n x r, host-generated RandomState(seed).normal, sklearn:utils/extmath.py:297)
+//   repeat n_iter:  Q <- PL(A Q);  Q <- PL(A^T Q)         (:349-351, scipy lu permute_l)
+//   Q <- qr_economic(A Q)                                   (:355)
+//   B = Q^T A;  Uhat, s, Vt = svd(B)                        (:579-588)
+//   svd_flip on the rows of Vt[:n_comp] (u_based_decision=False)   (_truncated_svd.py:253)
+//   X_new = A Vt[:n_comp]^T                                 (_truncated_svd.py:262)
+//
+// Device formulation: A is never dense.  A Q and A^T Q are gathers over CSR neighbour lists
+// (spmm.hip), B is held transposed (Bt = A^T Q, n x r), its SVD comes from the r x r Gram
+// Bt^T Bt (split-K MFMA GEMM, fixed-order reduction) and the Jacobi eigensolver, and
+// V = Bt U S^-1 is one more MFMA GEMM.  Everything is fp64: the embedding feeds k-means,
+// whose labels must match the CPU path bit for bit.  The whole sequence (~2000 small
+// launches) is captured once per shape into a hipGraph and replayed per window.
+#include "internal.h"
+
+namespace mused {
+
+struct Rsvd {
+  int n_max, r_max, eig_n, sweeps;
+  long nnz_cap;
+  unsigned long long *mask, *mask_t;
+  int *deg, *rowptr, *colidx, *degT, *rowptrT, *colidxT, *stats, *pivstep, *flags;
+  double *Q0, *Qa, *Qb, *Qf, *Bt, *prow, *tau, *wpart, *gpart, *evals, *U, *Cm, *Vsel, *embed, *sigma, *signs;
+  EigPlan* eig;
+  hipStream_t cap_stream;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  bool have_graph, use_graph;
+  int g_n, g_r, g_ncomp, g_iter;
+  int q0_n, q0_r;
+};
+
+constexpr int GRAM_KCHUNK = 512;
+
+__global__ void gram_reduce_pad_kernel(const double* __restrict__ partial, int nsplit, int rc, double* __restrict__ G,
+                                       int en) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= en * en) return;
+  const int i = gid / en, j = gid - i * en;
+  double s = 0.0;
+  if (i < rc && j < rc) {
+    // symmetrise by construction: entry (i, j) and (j, i) read the same partials in the same order
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    for (int z = 0; z < nsplit; ++z) s += partial[(long)z * rc * rc + (long)a * rc + b];
+  }
+  G[gid] = s;
+}
+
+// eigenvalues (unsorted, en) + eigenvectors U (en x en) of the Gram -> singular values (descending)
+// and the coefficient block Cm (rc x n_comp) = U[:, order] * diag(1 / s)
+__global__ __launch_bounds__(1024) void rsvd_decide_kernel(const double* __restrict__ evals, const double* __restrict__ U,
+                                                          int en, int rc, int n_comp, double* __restrict__ Cm,
+                                                          double* __restrict__ sigma) {
+  __shared__ int order[1024];
+  __shared__ double lam[1024];
+  const int t = threadIdx.x;
+  if (t < en) lam[t] = evals[t];
+  __syncthreads();
+  if (t < en) {
+    const double mine = lam[t];
+    int rank = 0;
+    for (int j = 0; j < en; ++j) {
+      const double o = lam[j];
+      rank += (o > mine) || (o == mine && j < t);
+    }
+    order[rank] = t;
+  }
+  __syncthreads();
+  const double l0 = lam[order[0]];
+  const double s0 = sqrt(l0 > 0.0 ? l0 : 0.0);
+  for (int i = t; i < n_comp; i += 1024) {
+    const double l = lam[order[i]];
+    sigma[i] = sqrt(l > 0.0 ? l : 0.0);
+  }
+  for (int e = t; e < rc * n_comp; e += 1024) {
+    const int a = e / n_comp, i = e - a * n_comp;
+    const int j = order[i];
+    const double l = lam[j];
+    const double s = sqrt(l > 0.0 ? l : 0.0);
+    Cm[e] = (s > 1e-12 * s0 && s > 0.0) ? U[(long)a * en + j] / s : 0.0;
+  }
+}
+
+// svd_flip(u_based_decision=False): per component, the entry of largest magnitude (first index
+// on ties) decides the sign (sklearn:utils/extmath.py:944-952).  One workgroup per column.
+__global__ __launch_bounds__(256) void col_sign_kernel(const double* __restrict__ V, int n, int ld, int ncol,
+                                                      double* __restrict__ signs) {
+  __shared__ double sv[4];
+  __shared__ int si[4];
+  const int c = blockIdx.x;
+  double best = -1.0;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double a = fabs(V[(long)i * ld + c]);
+    if (a > best || (a == best && i < bi)) { best = a; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    const double v = V[(long)bi * ld + c];
+    signs[c] = v < 0.0 ? -1.0 : 1.0;
+  }
+}
+
+__global__ void col_scale_kernel(double* __restrict__ V, long total, int ncol, const double* __restrict__ signs) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < total) V[gid] *= signs[gid % ncol];
+}
+
+static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream_t st) {
+  const int words = (n + 63) / 64;
+  const long ld = r;
+  int rc_;
+  static const bool dbg = getenv("MUSED_DEBUG") != nullptr;
+  int stage = 0;
+#define RC(x)                                                                                     \
+  do {                                                                                            \
+    if ((rc_ = (x))) return rc_;                                                                  \
+    ++stage;                                                                                      \
+    if (dbg) {                                                                                    \
+      hipError_t e_ = hipStreamSynchronize(st);                                                   \
+      fprintf(stderr, "[rsvd] stage %d (%s): %s\n", stage, #x, hipGetErrorString(e_));            \
+      if (e_ != hipSuccess) { set_error("stage %d failed: %s", stage, hipGetErrorString(e_)); return MUSED_ERR_HIP; } \
+    }                                                                                             \
+  } while (0)
+  if ((rc_ = zero_ints(h->flags, 4, st))) return rc_;
+  RC(adj_csr_from_mask(h->mask, n, words, h->deg, h->rowptr, h->colidx, h->stats, h->nnz_cap, h->flags, st));
+  RC(adj_transpose(h->mask, n, words, h->mask_t, st));
+  RC(adj_csr_from_mask(h->mask_t, n, words, h->degT, h->rowptrT, h->colidxT, h->stats + 2, h->nnz_cap, h->flags, st));
+
+  int rc = r;
+  const double* Qcur = h->Q0;
+  for (int it = 0; it < n_iter; ++it) {
+    RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
+    RC(lu_permute_l(h->Qa, n, rc, ld, h->pivstep, h->prow, st));
+    rc = n < rc ? n : rc;
+    RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qa, ld, rc, h->Qb, ld, st));
+    RC(lu_permute_l(h->Qb, n, rc, ld, h->pivstep, h->prow, st));
+    Qcur = h->Qb;
+  }
+  RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
+  rc = n < rc ? n : rc;
+  RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st));
+  RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qf, ld, rc, h->Bt, ld, st));
+
+  const int nsplit = cdiv(n, GRAM_KCHUNK);
+  RC(gemm_f64_splitk(false, false, h->Bt, ld, h->Bt, ld, h->gpart, rc, rc, n, GRAM_KCHUNK, nsplit, st));
+  const int en = h->eig_n;
+  hipLaunchKernelGGL(gram_reduce_pad_kernel, dim3(cdiv((long)en * en, 256)), dim3(256), 0, st, h->gpart, nsplit, rc,
+                     eig_plan_input(h->eig), en);
+  RC(eig_plan_run_inplace(h->eig, h->evals, h->U, st, false));
+  hipLaunchKernelGGL(rsvd_decide_kernel, dim3(1), dim3(1024), 0, st, h->evals, h->U, en, rc, n_comp, h->Cm, h->sigma);
+  RC(gemm_f64(true, false, h->Bt, ld, 0, h->Cm, n_comp, 0, h->Vsel, n_comp, 0, n, n_comp, rc, 1, 1.0, st));
+  hipLaunchKernelGGL(col_sign_kernel, dim3(n_comp), dim3(256), 0, st, h->Vsel, n, n_comp, n_comp, h->signs);
+  hipLaunchKernelGGL(col_scale_kernel, dim3(cdiv((long)n * n_comp, 256)), dim3(256), 0, st, h->Vsel, (long)n * n_comp,
+                     n_comp, h->signs);
+  RC(spmm_binary(h->rowptr, h->colidx, n, h->Vsel, n_comp, n_comp, h->embed, n_comp, st));
+  MUSED_LAUNCH_CHECK();
+#undef RC
+  return MUSED_OK;
+}
+
+static void rsvd_drop_graph(Rsvd* h) {
+  if (h->have_graph) {
+    (void)hipGraphExecDestroy(h->exec);
+    (void)hipGraphDestroy(h->graph);
+    h->have_graph = false;
+  }
+}
+
+}  // namespace mused
+
+using namespace mused;
+
+extern "C" {
+
+// Workspace handle for problems up to n_max rows, r_max = n_components + n_oversamples random
+// columns, nnz_cap edges in the fused adjacency.  `sweeps` = Jacobi sweeps of the r x r solve
+// (0 -> default 12).
+int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out) {
+  MUSED_REQUIRE(out && n_max >= 2 && r_max >= 1 && r_max <= 1022 && nnz_cap >= 1, "mused_rsvd_create: bad arguments");
+  Rsvd* h = new Rsvd();
+  memset(h, 0, sizeof(*h));
+  h->n_max = n_max; h->r_max = r_max; h->nnz_cap = nnz_cap;
+  h->sweeps = sweeps > 0 ? sweeps : 12;
+  h->eig_n = (r_max + 1) & ~1;
+  const size_t words = (n_max + 63) / 64;
+  const size_t panel = sizeof(double) * (size_t)n_max * r_max;
+  const int nsplit = cdiv(n_max, GRAM_KCHUNK);
+#define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))
+  ALLOC(h->mask, 8 * words * n_max);
+  ALLOC(h->mask_t, 8 * words * n_max);
+  ALLOC(h->deg, 4 * (size_t)n_max); ALLOC(h->degT, 4 * (size_t)n_max);
+  ALLOC(h->rowptr, 4 * (size_t)(n_max + 1)); ALLOC(h->rowptrT, 4 * (size_t)(n_max + 1));
+  ALLOC(h->colidx, 4 * (size_t)nnz_cap); ALLOC(h->colidxT, 4 * (size_t)nnz_cap);
+  ALLOC(h->stats, 4 * 8); ALLOC(h->flags, 4 * 4); ALLOC(h->pivstep, 4 * (size_t)n_max);
+  ALLOC(h->Q0, panel); ALLOC(h->Qa, panel); ALLOC(h->Qb, panel); ALLOC(h->Qf, panel); ALLOC(h->Bt, panel);
+  ALLOC(h->Vsel, panel); ALLOC(h->embed, panel);
+  ALLOC(h->prow, 8 * (size_t)r_max); ALLOC(h->tau, 8 * (size_t)r_max);
+  ALLOC(h->wpart, 8 * (size_t)r_max * cdiv(n_max, 512));
+  ALLOC(h->gpart, 8 * (size_t)nsplit * r_max * r_max);
+  ALLOC(h->evals, 8 * (size_t)h->eig_n); ALLOC(h->U, 8 * (size_t)h->eig_n * h->eig_n);
+  ALLOC(h->Cm, 8 * (size_t)r_max * r_max); ALLOC(h->sigma, 8 * (size_t)r_max); ALLOC(h->signs, 8 * (size_t)r_max);
+#undef ALLOC
+  int rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig);
+  if (rc) return rc;
+  if ((rc = gemm_f64_prepare_all())) return rc;
+  const char* ng = getenv("MUSED_NO_GRAPH");
+  h->use_graph = !(ng && ng[0] == '1');
+  if (h->use_graph) MUSED_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+  *out = h;
+  return MUSED_OK;
+}
+
+int mused_rsvd_destroy(void* handle) {
+  Rsvd* h = (Rsvd*)handle;
+  if (!h) return MUSED_OK;
+  rsvd_drop_graph(h);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  eig_plan_destroy(h->eig);
+  void* bufs[] = {h->mask, h->mask_t, h->deg, h->degT, h->rowptr, h->rowptrT, h->colidx, h->colidxT, h->stats,
+                  h->flags, h->pivstep, h->Q0, h->Qa, h->Qb, h->Qf, h->Bt, h->Vsel, h->embed, h->prow, h->tau,
+                  h->wpart, h->gpart, h->evals, h->U, h->Cm, h->sigma, h->signs};
+  for (void* b : bufs) (void)hipFree(b);
+  delete h;
+  return MUSED_OK;
+}
+
+// Device buffer the fused adjacency bitmask must be written to before mused_rsvd_reduce
+// (n rows of ceil(n/64) words, pitch ceil(n/64)).
+unsigned long long* mused_rsvd_mask_buffer(void* handle) { return handle ? ((Rsvd*)handle)->mask : nullptr; }
+
+// Q0: the (n x r) Gaussian test matrix, row-major fp64, generated on the host exactly as
+// sklearn does (np.random.RandomState(seed).normal(size=(n, r))).  Copied into the handle.
+int mused_rsvd_set_q0(void* handle, const double* Q0, int n, int r, void* stream) {
+  Rsvd* h = (Rsvd*)handle;
+  MUSED_REQUIRE(h && Q0 && n >= 1 && n <= h->n_max && r >= 1 && r <= h->r_max, "mused_rsvd_set_q0: bad arguments");
+  MUSED_CHECK_HIP(hipMemcpyAsync(h->Q0, Q0, sizeof(double) * (size_t)n * r, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+  h->q0_n = n; h->q0_r = r;
+  return MUSED_OK;
+}
+
+// Replaces perform_svd_reduction(matrix, reduced_dim, seed) for the fused 0/1 adjacency held as a
+// bitmask in the handle's mask buffer.  n_comp = min(reduced_dim, n - 1), r = n_comp + 10 must
+// match the Q0 set before.  out_embed: n x n_comp fp64 (X @ Vt.T), out_sigma: n_comp singular
+// values (TruncatedSVD.singular_values_), out_components (optional): n x n_comp = Vt[:n_comp].T.
+int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double* out_embed, double* out_sigma,
+                      double* out_components, void* stream) {
+  Rsvd* h = (Rsvd*)handle;
+  MUSED_REQUIRE(h && out_embed && out_sigma, "mused_rsvd_reduce: null pointer");
+  MUSED_REQUIRE(n >= 2 && n <= h->n_max && r <= h->r_max && n_comp >= 1 && n_comp <= r && n_comp <= n && n_iter >= 0,
+                "mused_rsvd_reduce: bad sizes n=%d n_comp=%d r=%d", n, n_comp, r);
+  MUSED_REQUIRE(h->q0_n == n && h->q0_r == r, "mused_rsvd_reduce: Q0 was set for (%d, %d), need (%d, %d)", h->q0_n,
+                h->q0_r, n, r);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (h->use_graph) {
+    if (!h->have_graph || h->g_n != n || h->g_r != r || h->g_ncomp != n_comp || h->g_iter != n_iter) {
+      rsvd_drop_graph(h);
+      MUSED_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+      rc = rsvd_enqueue(h, n, r, n_comp, n_iter, h->cap_stream);
+      hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
+      if (rc || e != hipSuccess) {
+        if (!rc) set_error("mused_rsvd_reduce: graph capture failed (%s)", hipGetErrorString(e));
+        return rc ? rc : MUSED_ERR_HIP;
+      }
+      MUSED_CHECK_HIP(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
+      h->have_graph = true;
+      h->g_n = n; h->g_r = r; h->g_ncomp = n_comp; h->g_iter = n_iter;
+    }
+    MUSED_CHECK_HIP(hipGraphLaunch(h->exec, st));
+  } else {
+    if ((rc = rsvd_enqueue(h, n, r, n_comp, n_iter, st))) return rc;
+  }
+  MUSED_CHECK_HIP(hipMemcpyAsync(out_embed, h->embed, sizeof(double) * (size_t)n * n_comp, hipMemcpyDeviceToDevice, st));
+  MUSED_CHECK_HIP(hipMemcpyAsync(out_sigma, h->sigma, sizeof(double) * (size_t)n_comp, hipMemcpyDeviceToDevice, st));
+  if (out_components)
+    MUSED_CHECK_HIP(hipMemcpyAsync(out_components, h->Vsel, sizeof(double) * (size_t)n * n_comp,
+                                   hipMemcpyDeviceToDevice, st));
+  return MUSED_OK;
+}
+
+// Blocking status read: flags[0] != 0 -> the adjacency had more than nnz_cap edges (results invalid);
+// stats = {max out-degree, nnz, max in-degree, nnz}.
+int mused_rsvd_status(void* handle, int* flags_out, int* stats_out, void* stream) {
+  Rsvd* h = (Rsvd*)handle;
+  MUSED_REQUIRE(h && flags_out && stats_out, "mused_rsvd_status: null pointer");
+  MUSED_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int tmp[8];
+  MUSED_CHECK_HIP(hipMemcpy(tmp, h->flags, sizeof(int) * 4, hipMemcpyDeviceToHost));
+  MUSED_CHECK_HIP(hipMemcpy(tmp + 4, h->stats, sizeof(int) * 4, hipMemcpyDeviceToHost));
+  flags_out[0] = tmp[0];
+  for (int k = 0; k < 4; ++k) stats_out[k] = tmp[4 + k];
+  return MUSED_OK;
+}
+
+}  // extern "C"

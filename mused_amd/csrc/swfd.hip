@@ -1,0 +1,569 @@
+// a5-a7 of SURVEY section 8: SeqBasedSWFD -- the sequence-based sliding-window Frequent
+// Directions sketch mused imports from its (un-vendored) `swfd` submodule (main.py:10,62,67,70).
+// The algorithm is this repo's specification (oracle/swfd_oracle.py):
+// L = ceil(log2 R) + 1 dump-snapshot levels, theta_j = 2^j N / l, a MAIN and an AUX sketch per
+// level; all 2L sketches rotate together every l rows of the current epoch (and at the epoch
+// end), AUX replaces MAIN at every epoch start.
+//
+// Device formulation of one rotation ("the per-window SVD/rotation step"), batched over the
+// S = 2L sketches, every sketch a (2l x d) fp64 buffer [kept rows ; pending rows ; zeros]:
+//     G_s   = buf_s buf_s^T                    (2l x 2l)   MFMA fp64 GEMM, K = d
+//     G_s   = U diag(lam) U^T                              batched Jacobi (eig.hip)
+//     decide: sort lam, delta = lam[l-1], s2 = max(lam - delta, 0); rows with s2 >= theta_s are
+//             dumped to the snapshot ring, the rest kept; Wc_s = diag(sqrt(s2/lam)) U[:, top l]^T
+//     T_s   = Wc_s buf_s                       (l x d)     MFMA fp64 GEMM, K = 2l
+//     scatter T_s rows to buf_s (kept) / snapshot ring (dumped), zero the tail.
+// Control flow is data independent (the rotation schedule depends only on the row counter),
+// all data-dependent decisions (dumps, expiry, level choice) stay on the device: no host sync
+// anywhere on the update or query path.
+#include "internal.h"
+
+namespace mused {
+
+struct Swfd {
+  int N, d, ell, L, S, cap, n2, n4;
+  double R;
+  long i;    // rows seen so far
+  int pend;  // rows appended since the last rotation (they sit raw in every buffer)
+  long restart_mark;  // value of i for which the epoch-start swap has already been done
+  int sweeps;
+  // persistent state
+  double* buf;         // S x n2 x d
+  double* queue;       // S x cap x d
+  long long* qt;       // S x cap   snapshot timestamps
+  int* meta;           // S x 4     {nk, qhead, qcount, unused}
+  long long* dropped;  // S         largest timestamp of a snapshot lost to the ring capacity
+  double* theta;       // S
+  // rotation workspace
+  double *T, *Wc, *evals, *U;
+  int* plan;      // S x ell x 2  {kind (0 none, 1 keep, 2 dump), position}
+  int* keep_src;  // S x ell      buffer position -> row of T
+  long long* now_dev;
+  EigPlan* eig;
+  // query workspace
+  double *stack, *evals_q, *Uq, *Wq, *Bout, *sig_out, *qinfo;
+  int* qsel;  // {level, nsnap, nk, slots[cap]}
+  EigPlan* eigq;
+};
+
+static inline int sk_index(const Swfd* h, int level, int kind) { return kind * h->L + level; }
+
+// ---- update ------------------------------------------------------------------------
+template <typename T>
+__global__ void swfd_append_kernel(const T* __restrict__ X, long ldx, int m, int d, int n2, int pend,
+                                   const int* __restrict__ meta, double* __restrict__ buf) {
+  const int r = blockIdx.x, s = blockIdx.y;
+  const int row = meta[s * 4 + 0] + pend + r;
+  if (row >= n2) return;  // cannot happen by construction (nk <= l - 1, pend + m <= l)
+  double* dst = buf + ((long)s * n2 + row) * d;
+  const T* src = X + (long)r * ldx;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = (double)src[c];
+}
+
+// epoch start: MAIN <- AUX, AUX <- empty  (sketch index = kind * L + level)
+__global__ void swfd_restart_kernel(double* __restrict__ buf, double* __restrict__ queue, long long* __restrict__ qt,
+                                    int* __restrict__ meta, long long* __restrict__ dropped, int L, long buf_elems,
+                                    long queue_elems, int cap) {
+  const int j = blockIdx.y;
+  const int sm = j, sa = L + j;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < buf_elems) {
+    buf[sm * buf_elems + gid] = buf[sa * buf_elems + gid];
+    buf[sa * buf_elems + gid] = 0.0;
+  }
+  if (gid < queue_elems) queue[sm * queue_elems + gid] = queue[sa * queue_elems + gid];
+  if (gid < cap) qt[sm * cap + gid] = qt[sa * cap + gid];
+  if (gid == 0) {
+    for (int k = 0; k < 4; ++k) {
+      meta[sm * 4 + k] = meta[sa * 4 + k];
+      meta[sa * 4 + k] = 0;
+    }
+    dropped[sm] = dropped[sa];
+    dropped[sa] = 0;
+  }
+}
+
+__global__ void swfd_set_now_kernel(long long* now, long long v) { *now = v; }
+
+// One workgroup per sketch: expiry, eigenvalue ordering, shrink, dump/keep plan, Wc.
+__global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restrict__ evals,
+                                                          const double* __restrict__ U, int n2, int ell, int cap,
+                                                          int N, const long long* __restrict__ now_p,
+                                                          const double* __restrict__ theta, int* __restrict__ meta,
+                                                          long long* __restrict__ qt, long long* __restrict__ dropped,
+                                                          int* __restrict__ plan, int* __restrict__ keep_src,
+                                                          double* __restrict__ Wc) {
+  __shared__ double lam[1024];
+  __shared__ int order[1024];
+  __shared__ double scale[512];  // sqrt(s2 / lam) of the top-l rows (0 = discarded)
+  const int s = blockIdx.x, t = threadIdx.x;
+  const long long now = *now_p;
+  const double* ev = evals + (long)s * n2;
+  const double* Us = U + (long)s * n2 * n2;
+  if (t < n2) lam[t] = ev[t];
+  __syncthreads();
+  if (t < n2) {
+    const double mine = lam[t];
+    int rank = 0;
+    for (int j = 0; j < n2; ++j) {
+      const double o = lam[j];
+      rank += (o > mine) || (o == mine && j < t);
+    }
+    order[rank] = t;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int nk = 0, head = meta[s * 4 + 1], cnt = meta[s * 4 + 2];
+    long long drop = dropped[s];
+    long long* q = qt + (long)s * cap;
+    while (cnt > 0 && q[head] + N <= now) {  // expiry
+      head = (head + 1) % cap;
+      --cnt;
+    }
+    const double l0 = lam[order[0]];
+    const double delta = lam[order[ell - 1]] > 0.0 ? lam[order[ell - 1]] : 0.0;
+    const double tol = 1e-10 * (l0 > 0.0 ? l0 : 0.0);
+    const double th = theta[s];
+    for (int i = 0; i < ell; ++i) {
+      const double l = lam[order[i]];
+      double s2 = l - delta;
+      s2 = s2 > 0.0 ? s2 : 0.0;
+      int kind = 0, pos = 0;
+      double sc = 0.0;
+      if (s2 > tol) {
+        sc = sqrt(s2 / l);
+        if (s2 >= th) {  // dump
+          if (cnt == cap) {
+            drop = q[head] > drop ? q[head] : drop;
+            head = (head + 1) % cap;
+            --cnt;
+          }
+          pos = (head + cnt) % cap;
+          q[pos] = now;
+          ++cnt;
+          kind = 2;
+        } else {
+          pos = nk;
+          keep_src[s * ell + nk] = i;
+          ++nk;
+          kind = 1;
+        }
+      }
+      plan[(s * ell + i) * 2 + 0] = kind;
+      plan[(s * ell + i) * 2 + 1] = pos;
+      scale[i] = sc;
+    }
+    meta[s * 4 + 0] = nk;
+    meta[s * 4 + 1] = head;
+    meta[s * 4 + 2] = cnt;
+    dropped[s] = drop;
+  }
+  __syncthreads();
+  double* W = Wc + (long)s * ell * n2;
+  for (int e = t; e < ell * n2; e += 1024) {
+    const int i = e / n2, a = e - i * n2;
+    const double sc = scale[i];
+    W[e] = (sc != 0.0) ? sc * Us[(long)a * n2 + order[i]] : 0.0;
+  }
+}
+
+// rows of T -> kept positions of buf / snapshot ring; buffer rows >= nk are cleared
+__global__ void swfd_scatter_kernel(const double* __restrict__ T, const int* __restrict__ plan,
+                                    const int* __restrict__ keep_src, const int* __restrict__ meta,
+                                    double* __restrict__ buf, double* __restrict__ queue, int n2, int ell, int cap,
+                                    int d) {
+  const int rho = blockIdx.x, s = blockIdx.y;
+  const double* Ts = T + (long)s * ell * d;
+  if (rho < ell && plan[(s * ell + rho) * 2] == 2) {
+    const int slot = plan[(s * ell + rho) * 2 + 1];
+    double* dst = queue + ((long)s * cap + slot) * d;
+    const double* src = Ts + (long)rho * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src[c];
+  }
+  const int nk = meta[s * 4 + 0];
+  double* dst = buf + ((long)s * n2 + rho) * d;
+  if (rho < nk) {
+    const double* src = Ts + (long)keep_src[s * ell + rho] * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src[c];
+  } else {
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = 0.0;
+  }
+}
+
+static int swfd_rotate_all(Swfd* h, hipStream_t st) {
+  const int S = h->S, n2 = h->n2, d = h->d, ell = h->ell;
+  int rc;
+  hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
+  if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
+                     (long)n2 * n2, n2, n2, d, S, 1.0, st)))
+    return rc;
+  if ((rc = eig_plan_run_inplace(h->eig, h->evals, h->U, st, true))) return rc;
+  hipLaunchKernelGGL(swfd_decide_kernel, dim3(S), dim3(1024), 0, st, h->evals, h->U, n2, ell, h->cap, h->N,
+                     h->now_dev, h->theta, h->meta, h->qt, h->dropped, h->plan, h->keep_src, h->Wc);
+  if ((rc = gemm_f64(true, false, h->Wc, n2, (long)ell * n2, h->buf, d, (long)n2 * d, h->T, d, (long)ell * d, ell, d,
+                     n2, S, 1.0, st)))
+    return rc;
+  hipLaunchKernelGGL(swfd_scatter_kernel, dim3(n2, S), dim3(256), 0, st, h->T, h->plan, h->keep_src, h->meta, h->buf,
+                     h->queue, n2, ell, h->cap, d);
+  MUSED_LAUNCH_CHECK();
+  h->pend = 0;
+  return MUSED_OK;
+}
+
+static int swfd_restart(Swfd* h, hipStream_t st) {
+  const long be = (long)h->n2 * h->d, qe = (long)h->cap * h->d;
+  const long m = be > qe ? be : qe;
+  hipLaunchKernelGGL(swfd_restart_kernel, dim3(cdiv(m, 256), h->L), dim3(256), 0, st, h->buf, h->queue, h->qt,
+                     h->meta, h->dropped, h->L, be, qe, h->cap);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
+template <typename T>
+static int swfd_append_t(Swfd* h, const T* X, long ldx, long m, hipStream_t st) {
+  long r = 0;
+  int rc;
+  while (r < m) {
+    if (h->i > 0 && h->i % h->N == 0 && h->restart_mark != h->i) {
+      // first row of a new epoch (pend == 0 here: the epoch-end rotation has run)
+      if ((rc = swfd_restart(h, st))) return rc;
+      h->restart_mark = h->i;
+    }
+    const long in_epoch = h->i % h->N;
+    long until = h->ell - (in_epoch % h->ell);
+    if (h->N - in_epoch < until) until = h->N - in_epoch;
+    const long take = (m - r) < until ? (m - r) : until;
+    hipLaunchKernelGGL(swfd_append_kernel<T>, dim3((int)take, h->S), dim3(256), 0, st, X + r * ldx, ldx, (int)take,
+                       h->d, h->n2, h->pend, h->meta, h->buf);
+    MUSED_LAUNCH_CHECK();
+    h->pend += (int)take;
+    h->i += take;
+    r += take;
+    if (take == until) {
+      if ((rc = swfd_rotate_all(h, st))) return rc;
+    }
+  }
+  return MUSED_OK;
+}
+
+// ---- query ---------------------------------------------------------------------------
+__global__ void swfd_select_kernel(const int* __restrict__ meta, const long long* __restrict__ qt,
+                                   const long long* __restrict__ dropped, int L, int cap, int N, long long now,
+                                   int* __restrict__ qsel) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int lvl = L - 1;
+  for (int j = 0; j < L; ++j) {
+    const long long dr = dropped[j];  // MAIN sketches are indices 0 .. L-1
+    if (dr == 0 || dr + N <= now) { lvl = j; break; }
+  }
+  const int head = meta[lvl * 4 + 1], cnt = meta[lvl * 4 + 2];
+  int ns = 0;
+  for (int q = 0; q < cnt; ++q) {
+    const int slot = (head + q) % cap;
+    if (qt[(long)lvl * cap + slot] + N > now) qsel[3 + ns++] = slot;
+  }
+  qsel[0] = lvl;
+  qsel[1] = ns;
+  qsel[2] = meta[lvl * 4 + 0];
+}
+
+__global__ void swfd_stack_kernel(const int* __restrict__ qsel, const double* __restrict__ buf,
+                                  const double* __restrict__ queue, int n2, int cap, int d, int pend,
+                                  double* __restrict__ stack) {
+  const int rho = blockIdx.x;
+  const int lvl = qsel[0], ns = qsel[1], nk = qsel[2];
+  const double* src = nullptr;
+  if (rho < ns) src = queue + ((long)lvl * cap + qsel[3 + rho]) * d;
+  else if (rho < ns + nk + pend) src = buf + ((long)lvl * n2 + (rho - ns)) * d;
+  double* dst = stack + (long)rho * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src ? src[c] : 0.0;
+}
+
+__global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* __restrict__ evals,
+                                                                const double* __restrict__ U, int n4, int ell,
+                                                                const int* __restrict__ qsel, double* __restrict__ Wq,
+                                                                double* __restrict__ qinfo) {
+  __shared__ double lam[1024];
+  __shared__ int order[1024];
+  __shared__ double scale[512];
+  const int t = threadIdx.x;
+  if (t < n4) lam[t] = evals[t];
+  __syncthreads();
+  if (t < n4) {
+    const double mine = lam[t];
+    int rank = 0;
+    for (int j = 0; j < n4; ++j) {
+      const double o = lam[j];
+      rank += (o > mine) || (o == mine && j < t);
+    }
+    order[rank] = t;
+  }
+  __syncthreads();
+  const double l0 = lam[order[0]];
+  const double delta = lam[order[ell - 1]] > 0.0 ? lam[order[ell - 1]] : 0.0;
+  const double tol = 1e-10 * (l0 > 0.0 ? l0 : 0.0);
+  if (t < ell) {
+    const double l = lam[order[t]];
+    double s2 = l - delta;
+    s2 = s2 > 0.0 ? s2 : 0.0;
+    scale[t] = (s2 > tol) ? sqrt(s2 / l) : 0.0;
+  }
+  if (t == 0) {
+    qinfo[0] = (double)qsel[0];
+    qinfo[1] = delta;
+  }
+  __syncthreads();
+  for (int e = t; e < ell * n4; e += 1024) {
+    const int i = e / n4, a = e - i * n4;
+    const double sc = scale[i];
+    Wq[e] = (sc != 0.0) ? sc * U[(long)a * n4 + order[i]] : 0.0;
+  }
+}
+
+// per output row: largest-magnitude entry made positive (first index on ties), sigma = row norm
+__global__ __launch_bounds__(256) void swfd_finish_rows_kernel(double* __restrict__ B, int d, double* __restrict__ sig) {
+  __shared__ double sv[4];
+  __shared__ int si[4];
+  __shared__ double ss[4];
+  __shared__ double s_sign;
+  double* row = B + (long)blockIdx.x * d;
+  double best = -1.0, sq = 0.0;
+  int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const double v = row[c];
+    const double a = fabs(v);
+    sq += v * v;
+    if (a > best || (a == best && c < bi)) { best = a; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    sq += __shfl_xor(sq, o);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; ss[threadIdx.x >> 6] = sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    s_sign = (row[bi] < 0.0) ? -1.0 : 1.0;
+    sig[blockIdx.x] = sqrt(ss[0] + ss[1] + ss[2] + ss[3]);
+  }
+  __syncthreads();
+  if (s_sign < 0.0)
+    for (int c = threadIdx.x; c < d; c += 256) row[c] = -row[c];
+}
+
+static int swfd_query(Swfd* h, double* outB, double* outSigma, double* outInfo, hipStream_t st) {
+  const int n4 = h->n4, d = h->d, ell = h->ell;
+  int rc;
+  hipLaunchKernelGGL(swfd_select_kernel, dim3(1), dim3(64), 0, st, h->meta, h->qt, h->dropped, h->L, h->cap, h->N,
+                     (long long)h->i, h->qsel);
+  hipLaunchKernelGGL(swfd_stack_kernel, dim3(n4), dim3(256), 0, st, h->qsel, h->buf, h->queue, h->n2, h->cap, d,
+                     h->pend, h->stack);
+  if ((rc = gemm_f64(true, true, h->stack, d, 0, h->stack, d, 0, eig_plan_input(h->eigq), n4, 0, n4, n4, d, 1, 1.0,
+                     st)))
+    return rc;
+  if ((rc = eig_plan_run_inplace(h->eigq, h->evals_q, h->Uq, st, true))) return rc;
+  hipLaunchKernelGGL(swfd_decide_query_kernel, dim3(1), dim3(1024), 0, st, h->evals_q, h->Uq, n4, ell, h->qsel, h->Wq,
+                     h->qinfo);
+  if ((rc = gemm_f64(true, false, h->Wq, n4, 0, h->stack, d, 0, h->Bout, d, 0, ell, d, n4, 1, 1.0, st))) return rc;
+  hipLaunchKernelGGL(swfd_finish_rows_kernel, dim3(ell), dim3(256), 0, st, h->Bout, d, h->sig_out);
+  MUSED_LAUNCH_CHECK();
+  MUSED_CHECK_HIP(hipMemcpyAsync(outB, h->Bout, sizeof(double) * (size_t)ell * d, hipMemcpyDeviceToDevice, st));
+  if (outSigma)
+    MUSED_CHECK_HIP(hipMemcpyAsync(outSigma, h->sig_out, sizeof(double) * (size_t)ell, hipMemcpyDeviceToDevice, st));
+  if (outInfo) MUSED_CHECK_HIP(hipMemcpyAsync(outInfo, h->qinfo, sizeof(double) * 2, hipMemcpyDeviceToDevice, st));
+  return MUSED_OK;
+}
+
+static size_t swfd_half_bytes(const Swfd* h) {
+  const size_t L = h->L;
+  return L * ((size_t)h->n2 * h->d * 8 + (size_t)h->cap * h->d * 8 + (size_t)h->cap * 8 + 4 * 4 + 8);
+}
+
+}  // namespace mused
+
+using namespace mused;
+
+extern "C" {
+
+// Replaces SeqBasedSWFD.__init__ (call site main.py:62: N=window_size, R=max row norm^2,
+// d=row length, sketch_dim=l).  sweeps: Jacobi sweeps per rotation (0 -> default).
+int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) {
+  MUSED_REQUIRE(out && N >= 1 && d >= 1 && ell >= 1 && ell <= 256, "mused_swfd_create: need N, d >= 1 and 1 <= sketch_dim <= 256");
+  MUSED_REQUIRE(N < (1l << 31), "mused_swfd_create: N too large");
+  Swfd* h = new Swfd();
+  memset(h, 0, sizeof(*h));
+  h->N = (int)N; h->R = R; h->d = d; h->ell = ell;
+  double r1 = R > 1.0 ? R : 1.0;
+  int lg = 0;
+  while ((double)(1ull << lg) < r1 && lg < 62) ++lg;  // ceil(log2(R))
+  h->L = lg + 1;
+  h->S = 2 * h->L;
+  h->cap = 2 * ell;
+  h->n2 = 2 * ell;
+  h->n4 = 4 * ell;
+  h->sweeps = sweeps > 0 ? sweeps : 12;
+  h->restart_mark = -1;
+  const size_t S = h->S, n2 = h->n2, n4 = h->n4, cap = h->cap, dd = d, l = ell;
+#define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))
+#define ZALLOC(p, bytes) do { ALLOC(p, bytes); MUSED_CHECK_HIP(hipMemset((p), 0, (bytes))); } while (0)
+  ZALLOC(h->buf, 8 * S * n2 * dd);
+  ZALLOC(h->queue, 8 * S * cap * dd);
+  ZALLOC(h->qt, 8 * S * cap);
+  ZALLOC(h->meta, 4 * S * 4);
+  ZALLOC(h->dropped, 8 * S);
+  ALLOC(h->theta, 8 * S);
+  ALLOC(h->T, 8 * S * l * dd); ALLOC(h->Wc, 8 * S * l * n2); ALLOC(h->evals, 8 * S * n2); ALLOC(h->U, 8 * S * n2 * n2);
+  ALLOC(h->plan, 4 * S * l * 2); ALLOC(h->keep_src, 4 * S * l); ALLOC(h->now_dev, 8);
+  ALLOC(h->stack, 8 * n4 * dd); ALLOC(h->evals_q, 8 * n4); ALLOC(h->Uq, 8 * n4 * n4); ALLOC(h->Wq, 8 * l * n4);
+  ALLOC(h->Bout, 8 * l * dd); ALLOC(h->sig_out, 8 * l); ALLOC(h->qinfo, 8 * 2); ALLOC(h->qsel, 4 * (3 + cap));
+#undef ZALLOC
+#undef ALLOC
+  double th[128];
+  for (int kind = 0; kind < 2; ++kind)
+    for (int j = 0; j < h->L; ++j) th[sk_index(h, j, kind)] = ldexp((double)h->N / ell, j);
+  MUSED_CHECK_HIP(hipMemcpy(h->theta, th, 8 * S, hipMemcpyHostToDevice));
+  int rc;
+  if ((rc = gemm_f64_prepare_all())) return rc;
+  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig))) return rc;
+  if ((rc = eig_plan_create(h->n4, 1, h->sweeps + 1, true, &h->eigq))) return rc;
+  *out = h;
+  return MUSED_OK;
+}
+
+int mused_swfd_destroy(void* handle) {
+  Swfd* h = (Swfd*)handle;
+  if (!h) return MUSED_OK;
+  eig_plan_destroy(h->eig);
+  eig_plan_destroy(h->eigq);
+  void* bufs[] = {h->buf, h->queue, h->qt, h->meta, h->dropped, h->theta, h->T, h->Wc, h->evals, h->U, h->plan,
+                  h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel};
+  for (void* b : bufs) (void)hipFree(b);
+  delete h;
+  return MUSED_OK;
+}
+
+int mused_swfd_levels(void* handle) { return handle ? ((Swfd*)handle)->L : -1; }
+
+// Replaces the per-row SeqBasedSWFD.fit(row) loop (main.py:65-67): appends n_rows rows of
+// length d (device pointer, row pitch ld elements, dtype MUSED_F32 / F64 / I64 -- the fused matrix
+// is int64 for >= 2 modalities, matrix_operations.py:138).  Any split of the stream into calls
+// gives the same sketch.
+int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, long ld, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && (rows || n_rows == 0) && n_rows >= 0 && ld >= h->d, "mused_swfd_append: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MUSED_F32) return swfd_append_t<float>(h, (const float*)rows, ld, n_rows, st);
+  if (dtype == MUSED_F64) return swfd_append_t<double>(h, (const double*)rows, ld, n_rows, st);
+  if (dtype == MUSED_I64) return swfd_append_t<long long>(h, (const long long*)rows, ld, n_rows, st);
+  set_error("mused_swfd_append: unsupported dtype %d", dtype);
+  return MUSED_ERR_UNSUPPORTED;
+}
+
+// Replaces SeqBasedSWFD.get() (main.py:70): out_sketch (l x d fp64), out_sigma (l, row norms of the
+// sketch = its singular values), out_info = {level used, delta of the final shrink}.  Device pointers.
+int mused_swfd_query(void* handle, double* out_sketch, double* out_sigma, double* out_info, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && out_sketch, "mused_swfd_query: null pointer");
+  return swfd_query(h, out_sketch, out_sigma, out_info, (hipStream_t)stream);
+}
+
+int mused_swfd_counters(void* handle, long* rows_seen, int* pending) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && rows_seen && pending, "mused_swfd_counters: null pointer");
+  *rows_seen = h->i;
+  *pending = h->pend;
+  return MUSED_OK;
+}
+
+// ---- state exchange between ranks (windows sharded over GPUs) --------------------
+// One "half" = the L sketches of one kind (0 = MAIN, 1 = AUX) packed as
+// [bufs | queues | timestamps | meta | dropped].
+long mused_swfd_half_bytes(void* handle) { return handle ? (long)swfd_half_bytes((Swfd*)handle) : -1; }
+
+static int half_copy(Swfd* h, int kind, char* blob, bool to_blob, hipStream_t st) {
+  const size_t L = h->L;
+  const size_t o = (size_t)kind * L;
+  struct Part { char* dev; size_t bytes; };
+  Part parts[5] = {
+      {(char*)(h->buf + o * h->n2 * h->d), L * h->n2 * h->d * 8},
+      {(char*)(h->queue + o * h->cap * h->d), L * (size_t)h->cap * h->d * 8},
+      {(char*)(h->qt + o * h->cap), L * (size_t)h->cap * 8},
+      {(char*)(h->meta + o * 4), L * 16},
+      {(char*)(h->dropped + o), L * 8},
+  };
+  size_t off = 0;
+  for (const Part& p : parts) {
+    if (to_blob) MUSED_CHECK_HIP(hipMemcpyAsync(blob + off, p.dev, p.bytes, hipMemcpyDeviceToDevice, st));
+    else MUSED_CHECK_HIP(hipMemcpyAsync(p.dev, blob + off, p.bytes, hipMemcpyDeviceToDevice, st));
+    off += p.bytes;
+  }
+  return MUSED_OK;
+}
+
+int mused_swfd_export_half(void* handle, int kind, void* dst, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && dst && (kind == 0 || kind == 1), "mused_swfd_export_half: bad arguments");
+  return half_copy(h, kind, (char*)dst, true, (hipStream_t)stream);
+}
+
+int mused_swfd_import_half(void* handle, int kind, const void* src, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && src && (kind == 0 || kind == 1), "mused_swfd_import_half: bad arguments");
+  return half_copy(h, kind, (char*)src, false, (hipStream_t)stream);
+}
+
+// Start epoch e = rows_seen / N on this rank with the row counter set to `rows_seen` (a multiple
+// of N): AUX is cleared; MAIN is taken from `main_half` (the AUX half exported by the rank that
+// processed the previous window) or, if null, cleared as well (stream start).
+int mused_swfd_begin_epoch(void* handle, long rows_seen, const void* main_half, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && rows_seen >= 0 && rows_seen % h->N == 0, "mused_swfd_begin_epoch: rows_seen must be a multiple of N");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t S = h->S, L = h->L;
+  MUSED_CHECK_HIP(hipMemsetAsync(h->buf, 0, 8 * S * h->n2 * h->d, st));
+  MUSED_CHECK_HIP(hipMemsetAsync(h->meta, 0, 4 * S * 4, st));
+  MUSED_CHECK_HIP(hipMemsetAsync(h->dropped, 0, 8 * S, st));
+  MUSED_CHECK_HIP(hipMemsetAsync(h->qt, 0, 8 * S * h->cap, st));
+  (void)L;
+  if (main_half) {
+    int rc = half_copy(h, 0, (char*)main_half, false, st);
+    if (rc) return rc;
+  }
+  h->i = rows_seen;
+  h->pend = 0;
+  h->restart_mark = rows_seen;  // the epoch-start swap is what this call just did
+  return MUSED_OK;
+}
+
+}  // extern "C"
+
+// Unit-testable primitive: ONE Frequent-Directions rotation of a (2l x d) fp64 buffer in place
+// (the FD primitive of SURVEY Appendix A): rows <- sqrt(max(s^2 - s[l-1]^2, 0)) * Vt for the top l
+// directions (rows whose shrunk energy is <= 1e-10 s[0]^2 dropped, survivors packed first), rest
+// zeroed.  sigma_out (l doubles) receives the norms of the first l rows afterwards.  Builds and
+// frees its workspace per call: test/diagnostic use.
+extern "C" int mused_fd_rotate(double* buf, int ell, int d, double* sigma_out, int sweeps, void* stream) {
+  MUSED_REQUIRE(buf && sigma_out && ell >= 1 && d >= 1, "mused_fd_rotate: bad arguments");
+  void* hv = nullptr;
+  int rc = mused_swfd_create(1l << 30, 1.0, d, ell, sweeps, &hv);  // one level, theta = 2^30 / l: never dumps
+  if (rc) return rc;
+  mused::Swfd* h = (mused::Swfd*)hv;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bytes = sizeof(double) * (size_t)2 * ell * d;
+  hipError_t e = hipMemcpyAsync(h->buf, buf, bytes, hipMemcpyDeviceToDevice, st);
+  h->i = 2 * ell;
+  if (e == hipSuccess) rc = mused::swfd_rotate_all(h, st);
+  if (e == hipSuccess && !rc) e = hipMemcpyAsync(buf, h->buf, bytes, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && !rc) {
+    hipLaunchKernelGGL(mused::swfd_finish_rows_kernel, dim3(ell), dim3(256), 0, st, buf, d, sigma_out);
+    e = hipStreamSynchronize(st);
+  }
+  mused_swfd_destroy(hv);
+  if (rc) return rc;
+  MUSED_CHECK_HIP(e);
+  return MUSED_OK;
+}

@@ -1,0 +1,261 @@
+"""Device-resident window engine: the MI355X hot path behind the reference's Python call surface.
+
+One `WindowEngine` owns the persistent HBM workspaces for windows of up to `n_max` rows:
+
+    scores   n x n  fp64   pairwise scores of the current modality      (8 n^2 B, 800 MB at n = 10^4)
+    norms    n      fp64
+    masks    per-modality and fused adjacency BITMASKS, n x ceil(n/64) uint64 (12.5 MB at n = 10^4)
+    rsvd     handle of the randomized-SVD eigenstep (CSR lists, n x (l+10) panels, hipGraph)
+
+Nothing W x W and dense ever leaves the device unless the NumPy-compatible wrappers in
+`mused_amd.matrix_operations` ask for it.  torch is used for device memory and streams only;
+all arithmetic is in libmused_hip (ctypes, raw pointers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, F64, I64, METRIC_COSINE, METRIC_L2, MusedError, call
+
+_DT = {torch.float32: F32, torch.float64: F64, torch.int64: I64}
+
+
+def _require_gpu():
+    _lib.lib()  # raises if the extension is not built
+    if not torch.cuda.is_available():
+        raise MusedError("no HIP device visible: the mused_amd hot path has no CPU fallback")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def words_for(n: int) -> int:
+    return (n + 63) // 64
+
+
+def to_device_rows(data, device="cuda") -> torch.Tensor:
+    """Rows as a contiguous device tensor, keeping float32 / float64 (anything else -> float64)."""
+    if isinstance(data, torch.Tensor):
+        t = data
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.to(torch.float64)
+        return t.to(device).contiguous()
+    a = np.asarray(data)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+class Adjacency:
+    """A directed 0/1 adjacency held as an n x words uint64 bitmask on the device.
+
+    bit j of row i set  <=>  A[i, j] = 1   (matrix_operations.py:123-130: j among the selected
+    neighbours of i, j != i).  `fused` records which dtype the reference would return
+    (float64 copy for one modality, int64 after a logical_or; matrix_operations.py:135,138).
+    """
+
+    def __init__(self, mask: torch.Tensor, n: int, fused: bool = False):
+        self.mask = mask  # (n, words) int64 tensor viewed as uint64 words
+        self.n = n
+        self.words = mask.shape[1]
+        self.fused = fused
+
+    def to_dense(self, dtype=None) -> torch.Tensor:
+        if dtype is None:
+            dtype = torch.int64 if self.fused else torch.float64
+        out = torch.empty((self.n, self.n), dtype=dtype, device=self.mask.device)
+        call("mused_adj_to_dense", ptr(self.mask), self.n, self.words, _DT[dtype], ptr(out), stream_ptr())
+        return out
+
+    def to_numpy(self) -> np.ndarray:
+        return self.to_dense().cpu().numpy()
+
+    def degrees(self):
+        deg = torch.empty(self.n, dtype=torch.int32, device=self.mask.device)
+        rowptr = torch.empty(self.n + 1, dtype=torch.int32, device=self.mask.device)
+        stats = torch.empty(2, dtype=torch.int32, device=self.mask.device)
+        call("mused_adj_degrees", ptr(self.mask), self.n, self.words, ptr(deg), ptr(rowptr), ptr(stats), stream_ptr())
+        return deg, rowptr, stats
+
+    def neighbour_lists(self):
+        """(rowptr, colidx) int32 device tensors, columns ascending."""
+        deg, rowptr, stats = self.degrees()
+        nnz = int(stats[1].item())
+        colidx = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.mask.device)
+        call("mused_adj_csr_fill", ptr(self.mask), self.n, self.words, ptr(rowptr), ptr(colidx), stream_ptr())
+        return rowptr, colidx[:nnz]
+
+    @staticmethod
+    def from_dense(dense, device="cuda") -> "Adjacency":
+        """Import an n x n 0/1 matrix (NumPy or torch).  Raises on entries other than 0/1."""
+        if isinstance(dense, torch.Tensor):
+            t = dense.to(device)
+        else:
+            a = np.asarray(dense)
+            if a.dtype == np.bool_:
+                a = a.astype(np.int64)
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        if t.dtype not in _DT:
+            t = t.to(torch.float64)
+        t = t.contiguous()
+        if t.dim() != 2 or t.shape[0] != t.shape[1]:
+            raise ValueError("adjacency must be a square 2-D matrix")
+        n = t.shape[0]
+        w = words_for(n)
+        mask = torch.empty((n, w), dtype=torch.int64, device=device)
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
+        call("mused_adj_from_dense", ptr(t), _DT[t.dtype], n, n, w, ptr(mask), ptr(flag), stream_ptr())
+        if int(flag.item()):
+            raise NotImplementedError(
+                "only 0/1 adjacency matrices are supported on the device path "
+                "(the reference only ever passes the fused kNN adjacency, main.py:56,79)"
+            )
+        return Adjacency(mask, n, fused=(t.dtype == torch.int64))
+
+
+class WindowEngine:
+    """Workspaces + ops for windows of at most n_max rows (see module docstring)."""
+
+    def __init__(self, n_max: int, device="cuda"):
+        _require_gpu()
+        self.n_max = int(n_max)
+        self.device = device
+        self.scores = torch.empty(self.n_max * self.n_max, dtype=torch.float64, device=device)
+        self.norms = torch.empty(self.n_max, dtype=torch.float64, device=device)
+        self._rsvd = None
+        self._rsvd_key = None
+        self._rsvd_cap = 0
+        self._q0_key = None
+
+    # ---- a1 / a2 ------------------------------------------------------------------------
+    def knn_adjacency(self, rows, k: int, metric: str = "l2", want_idx: bool = False):
+        """Adjacency of the k selected rows per row (self removed).  `rows`: (n, d) float32/float64
+        device tensor with finite entries.  metric "l2": k = max(1, k_basis) nearest incl. self
+        (matrix_operations.py:113-119); "cosine": k_basis + 1 most similar (:93,108)."""
+        X = to_device_rows(rows, self.device)
+        n, d = X.shape
+        if n > self.n_max:
+            raise ValueError(f"window of {n} rows exceeds the engine capacity {self.n_max}")
+        if metric == "l2":
+            kk, m = max(1, int(k)), METRIC_L2
+            if kk > n:
+                # same error as sklearn's kneighbors (neighbors/_base.py)
+                raise ValueError(
+                    f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {kk}, "
+                    f"n_samples_fit = {n}, n_samples = {n}"
+                )
+        elif metric == "cosine":
+            kk, m = min(int(k) + 1, n), METRIC_COSINE
+        else:
+            raise ValueError(f"unknown metric {metric!r}")
+        w = words_for(n)
+        mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+        idx = torch.empty((n, kk), dtype=torch.int32, device=self.device) if want_idx else None
+        call(
+            "mused_knn_topk", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(self.scores), ptr(self.norms),
+            ptr(idx) if want_idx else None, ptr(mask), w, stream_ptr(),
+        )
+        adj = Adjacency(mask, n)
+        return (adj, idx) if want_idx else adj
+
+    # ---- a3 / a4 ------------------------------------------------------------------------
+    def fuse(self, adjs) -> Adjacency:
+        n, w = adjs[0].n, adjs[0].words
+        for a in adjs:
+            if a.n != n or a.words != w:
+                raise ValueError("adjacency shapes differ")
+        out = torch.empty((n, w), dtype=torch.int64, device=self.device)
+        arr = (C.c_void_p * len(adjs))(*[a.mask.data_ptr() for a in adjs])
+        call("mused_adj_fuse", arr, len(adjs), n, w, ptr(out), stream_ptr())
+        return Adjacency(out, n, fused=len(adjs) > 1)
+
+    @staticmethod
+    def max_row_sq_norm(adj: Adjacency) -> float:
+        """main.py:61 for a 0/1 matrix: max_i ||row_i||^2 = largest out-degree.  Blocking (.item())."""
+        _, _, stats = adj.degrees()
+        return float(stats[0].item())
+
+    # ---- a8 -------------------------------------------------------------------------------
+    def _rsvd_handle(self, n: int, r: int, nnz_cap: int):
+        if self._rsvd is None or self._rsvd_key[0] < n or self._rsvd_key[1] < r or self._rsvd_cap < nnz_cap:
+            if self._rsvd is not None:
+                call("mused_rsvd_destroy", self._rsvd)
+            h = C.c_void_p()
+            n_alloc = max(n, self.n_max)
+            call("mused_rsvd_create", n_alloc, r, nnz_cap, 0, C.byref(h))
+            self._rsvd, self._rsvd_key, self._rsvd_cap = h, (n_alloc, r), nnz_cap
+            self._q0_key = None
+        return self._rsvd
+
+    def svd_reduce(self, adj: Adjacency, reduced_dim: int, seed: int, n_iter: int = 5, n_oversamples: int = 10,
+                   nnz_cap: int | None = None, want_components: bool = False):
+        """perform_svd_reduction on a device adjacency: (embedding (n, n_comp), sigma (n_comp,)) fp64
+        device tensors.  Q0 is generated on the host exactly as sklearn does and cached per (n, r, seed)."""
+        n = adj.n
+        n_comp = min(int(reduced_dim), n - 1)
+        if n_comp < 1:
+            raise ValueError("need at least 2 columns")  # TruncatedSVD: ensure_min_features=2
+        r = n_comp + n_oversamples
+        if nnz_cap is None:
+            nnz_cap = int(adj.degrees()[2][1].item())  # blocking; callers on the fast path pass a bound
+        nnz_cap = max(int(nnz_cap), 1)
+        h = self._rsvd_handle(n, r, nnz_cap)
+        if self._q0_key != (n, r, seed):
+            q0 = np.random.RandomState(seed).normal(size=(n, r))
+            q0_dev = torch.from_numpy(q0).to(self.device)
+            call("mused_rsvd_set_q0", h, ptr(q0_dev), n, r, stream_ptr())  # stream-ordered copy
+            self._q0_key = (n, r, seed)
+        mbuf = _lib.lib().mused_rsvd_mask_buffer(h)
+        nbytes = n * adj.words * 8
+        _hip_memcpy_d2d(mbuf, adj.mask.data_ptr(), nbytes)
+        emb = torch.empty((n, n_comp), dtype=torch.float64, device=self.device)
+        sig = torch.empty(n_comp, dtype=torch.float64, device=self.device)
+        comp = torch.empty((n, n_comp), dtype=torch.float64, device=self.device) if want_components else None
+        call("mused_rsvd_reduce", h, n, n_comp, r, n_iter, ptr(emb), ptr(sig), ptr(comp) if want_components else None,
+             stream_ptr())
+        return (emb, sig, comp) if want_components else (emb, sig)
+
+    def rsvd_status(self):
+        flags, stats = (C.c_int * 1)(), (C.c_int * 4)()
+        call("mused_rsvd_status", self._rsvd, flags, stats, stream_ptr())
+        return int(flags[0]), [int(x) for x in stats]
+
+    def close(self):
+        if self._rsvd is not None:
+            call("mused_rsvd_destroy", self._rsvd)
+            self._rsvd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _hip_memcpy_d2d(dst_ptr: int, src_ptr: int, nbytes: int):
+    """Async device-to-device copy on torch's current stream between raw pointers."""
+    call("mused_memcpy_d2d", C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes, stream_ptr())
+
+
+_ENGINES: dict[int, WindowEngine] = {}
+
+
+def default_engine(n: int) -> WindowEngine:
+    """Process-wide engine able to hold windows of n rows (grown on demand)."""
+    for cap, eng in _ENGINES.items():
+        if cap >= n:
+            return eng
+    for eng in _ENGINES.values():
+        eng.close()
+    _ENGINES.clear()
+    _ENGINES[n] = WindowEngine(n)
+    return _ENGINES[n]

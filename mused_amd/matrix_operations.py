@@ -1,0 +1,219 @@
+"""MI355X-native stand-in for the reference's `matrix_operations` module.
+
+Same eight names `main.py:5` imports, same argument meaning, return types and error behaviour:
+
+    create_adjacency_matrix, fuse_matrices, match_clusters, perform_dbscan_clustering,
+    perform_svd_reduction, perform_clustering, perform_dbscan_incr_clustering,
+    perform_hdbscan_clustering
+
+The numerical hot path (similarity -> kNN adjacency, fusion, randomized-SVD eigenstep) runs in
+libmused_hip on the GPU through `mused_amd.engine.WindowEngine`; there is no CPU fallback -- without
+the built extension or without a HIP device these functions raise.  The consumers that turn the
+embedding into event indices (k-means, Hungarian matching) stay on the
+host and call scikit-learn / SciPy exactly where the reference does, so label parity reduces to
+embedding parity.
+
+Two call styles:
+  * NumPy in / NumPy out  -- drop-in for the reference (dense n x n matrices cross PCIe);
+  * device objects        -- pass / receive `engine.Adjacency` and torch CUDA tensors
+                             (`adjacency_on_device`, `fuse_matrices` on Adjacency objects,
+                             `svd_reduce_on_device`) and nothing W x W ever visits the host.
+
+Not on the device path: the metadata modality types of the SED2012
+dataset ("location", "time", "username", "tags", "text" on raw strings).  They raise
+NotImplementedError here; vectorised text rows can use modality_type="cosine".
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import engine as _eng
+
+_METADATA_TYPES = ("location", "time", "username", "tags", "text")
+
+
+def _metric_for(modality_type) -> str:
+    if modality_type in _METADATA_TYPES:
+        raise NotImplementedError(
+            f"modality_type={modality_type!r} works on SED2012 metadata columns (strings / two-column "
+            "records, matrix_operations.py:22-110) and is outside the device hot path; dense feature "
+            'rows use the default type (Euclidean kNN) or "cosine"'
+        )
+    return "cosine" if modality_type == "cosine" else "l2"
+
+
+def adjacency_on_device(data, modality_type="", k_basis=50, engine=None) -> _eng.Adjacency:
+    """Device-resident result of create_adjacency_matrix (matrix_operations.py:14-132, `case _`).
+
+    Rows with a non-finite entry are excluded from the kNN and get empty rows / columns
+    (matrix_operations.py:114-115, 126-127)."""
+    import torch
+
+    metric = _metric_for(modality_type)
+    if isinstance(data, torch.Tensor):
+        X = _eng.to_device_rows(data)
+        finite = torch.isfinite(X).all(dim=1)
+        all_valid = bool(finite.all().item())
+        valid_idx = None if all_valid else torch.nonzero(finite).flatten()
+    else:
+        a = np.asarray(data)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        fin = np.all(np.isfinite(a), axis=1)
+        all_valid = bool(fin.all())
+        valid_np = None if all_valid else np.where(fin)[0]
+        X = _eng.to_device_rows(a if all_valid else a[valid_np])
+        valid_idx = None if all_valid else torch.from_numpy(valid_np).to(X.device)
+        if not all_valid:
+            finite = None
+    n = len(data)
+    eng = engine or _eng.default_engine(n)
+    if all_valid:
+        return eng.knn_adjacency(X, k_basis, metric)
+    if isinstance(data, torch.Tensor):
+        X = X[valid_idx].contiguous()
+    if X.shape[0] == 0:
+        w = _eng.words_for(n)
+        return _eng.Adjacency(torch.zeros((n, w), dtype=torch.int64, device=eng.device), n)
+    sub = eng.knn_adjacency(X, k_basis, metric)
+    # scatter the valid-subset adjacency back to window coordinates (rare path: dense round trip)
+    dense = torch.zeros((n, n), dtype=torch.float64, device=X.device)
+    sd = sub.to_dense(torch.float64)
+    dense[valid_idx.unsqueeze(1), valid_idx.unsqueeze(0)] = sd
+    return _eng.Adjacency.from_dense(dense)
+
+
+def create_adjacency_matrix(data, modality_type, k_basis=50):
+    """matrix_operations.py:14: (n, n) float64 0/1 matrix, A[i, j] = 1 iff j is one of the
+    k selected neighbours of i and j != i."""
+    return adjacency_on_device(data, modality_type, k_basis).to_numpy()
+
+
+def fuse_matrices(matrices):
+    """matrix_operations.py:134-141.  A list of `Adjacency` objects gives a fused `Adjacency` (device
+    OR of bitmasks); a list of ndarrays gives what the reference returns: a float64 copy for one
+    matrix, the int64 logical OR for two or more."""
+    if len(matrices) == 0:
+        raise IndexError("list index out of range")  # matrices[0] in the reference
+    if all(isinstance(m, _eng.Adjacency) for m in matrices):
+        eng = _eng.default_engine(matrices[0].n)
+        return eng.fuse(list(matrices))
+    if len(matrices) == 1:
+        return np.array(matrices[0], copy=True)  # plain .copy(): no arithmetic to accelerate
+    adjs = [m if isinstance(m, _eng.Adjacency) else _eng.Adjacency.from_dense(np.asarray(m) != 0) for m in matrices]
+    eng = _eng.default_engine(adjs[0].n)
+    return eng.fuse(adjs).to_dense().cpu().numpy()
+
+
+def max_row_sq_norm(fused) -> float:
+    """R of main.py:61: max_i ||fused[i, :]||^2."""
+    if isinstance(fused, _eng.Adjacency):
+        return _eng.WindowEngine.max_row_sq_norm(fused)
+    return _eng.WindowEngine.max_row_sq_norm(_eng.Adjacency.from_dense(fused))
+
+
+def svd_reduce_on_device(matrix, reduced_dim, seed, nnz_cap=None, engine=None):
+    """(embedding, singular_values) as fp64 CUDA tensors; `matrix` an Adjacency or a dense 0/1 matrix."""
+    adj = matrix if isinstance(matrix, _eng.Adjacency) else _eng.Adjacency.from_dense(matrix)
+    eng = engine or _eng.default_engine(adj.n)
+    return eng.svd_reduce(adj, reduced_dim, seed, nnz_cap=nnz_cap)
+
+
+def perform_svd_reduction(matrix, reduced_dim, seed):
+    """matrix_operations.py:143-147: TruncatedSVD(n_components=min(reduced_dim, n_cols - 1),
+    random_state=seed).fit_transform(matrix) for the 0/1 fused adjacency -> (n, n_comp) float64."""
+    emb, _ = svd_reduce_on_device(matrix, reduced_dim, seed)
+    return emb.cpu().numpy()
+
+
+# ---- host-side consumers (keep on host, same library calls) ----------
+
+
+def perform_clustering(matrix, n_clusters, seed):
+    """matrix_operations.py:149-153."""
+    from sklearn.cluster import KMeans
+
+    if hasattr(matrix, "cpu"):
+        matrix = matrix.cpu().numpy()
+    return KMeans(n_clusters=n_clusters, random_state=seed).fit_predict(matrix)
+
+
+def _overlap_costs(prev_clusters, new_clusters, min_overlap):
+    up, un = np.unique(prev_clusters), np.unique(new_clusters)
+    cost = np.full((len(up), len(un)), np.inf)
+    for a, p in enumerate(up):
+        sel = prev_clusters == p
+        for b, q in enumerate(un):
+            ov = int(np.count_nonzero(sel & (new_clusters == q)))
+            if ov >= min_overlap:
+                cost[a, b] = -ov
+    return up, un, cost
+
+
+def _feasible(cost) -> bool:
+    inf = np.isinf(cost)
+    return not (inf.all() or inf.all(axis=1).any() or inf.all(axis=0).any())
+
+
+def match_clusters(prev_clusters, new_clusters, method="hungarian", min_overlap=5):
+    """matrix_operations.py:155-185: relabel the new window's clusters by the previous window's
+    labels through a minimum-cost assignment on positional overlap counts."""
+    if prev_clusters is None or len(prev_clusters) == 0:
+        return new_clusters
+    prev_clusters = np.asarray(prev_clusters)
+    new_arr = np.asarray(new_clusters)
+    up, un, cost = _overlap_costs(prev_clusters, new_arr, min_overlap)
+    if not _feasible(cost):
+        return new_clusters
+    if method == "hungarian":
+        from scipy.optimize import linear_sum_assignment
+
+        rows, cols = linear_sum_assignment(cost)
+        relabel = {un[c]: up[r] for r, c in zip(rows, cols)}
+        return np.array([relabel.get(c, c) for c in new_arr])
+    if method == "pot":
+        try:
+            import ot
+        except ImportError as e:  # the reference imports POT at module level (matrix_operations.py:12)
+            raise ImportError("match_clusters(method='pot') needs the POT package") from e
+        cost = np.abs(np.where(np.isinf(cost), 1e9, cost))
+        cost = cost / cost.max()
+        plan = ot.sinkhorn(np.full(len(up), 1.0 / len(up)), np.full(len(un), 1.0 / len(un)), cost, reg=0.1)
+        rows, cols = np.where(plan > plan.max() * 0.5)
+        relabel = {un[c]: up[r] for r, c in zip(rows, cols)}
+        return np.array([relabel.get(c, c) for c in new_arr])
+    raise ValueError("Invalid method. Choose 'hungarian' or 'pot'.")
+
+
+def perform_dbscan_clustering(data, eps=0.5, min_samples=5):
+    """matrix_operations.py:235-238."""
+    from sklearn.cluster import DBSCAN
+
+    return DBSCAN(eps=eps, min_samples=min_samples, metric="euclidean").fit_predict(data)
+
+
+def perform_hdbscan_clustering(data, min_cluster_size=5, min_samples=2):
+    """matrix_operations.py:240-243 (needs the optional `hdbscan` package, as the reference does)."""
+    import hdbscan
+
+    return hdbscan.HDBSCAN(min_cluster_size=min_cluster_size, min_samples=min_samples, metric="euclidean").fit_predict(data)
+
+
+def perform_dbscan_incr_clustering(data, previous_centroids, previous_labels, eps=0.5, min_samples=5):
+    """matrix_operations.py:265-298: DBSCAN on the window, clusters renamed after the closest
+    centroid of the previous window."""
+    from scipy.spatial.distance import cdist
+    from sklearn.cluster import DBSCAN
+
+    if not isinstance(data, np.ndarray):
+        data = np.array(data, dtype=np.float32)
+    if data.ndim != 2:
+        return None, previous_centroids, previous_labels
+    labels = DBSCAN(eps=eps, min_samples=min_samples, metric="euclidean").fit_predict(data)
+    found = set(labels) - {-1}
+    centroids = np.array([data[labels == c].mean(axis=0) for c in found])
+    if previous_centroids is not None and len(previous_centroids) > 0:
+        nearest = np.argmin(cdist(centroids, previous_centroids), axis=1)
+        rename = {new: (previous_labels[old] if old < len(previous_labels) else -1) for new, old in enumerate(nearest)}
+        labels = np.array([rename[l] if l in rename else l for l in labels])
+    return labels, centroids, np.unique(labels)

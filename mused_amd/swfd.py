@@ -1,0 +1,134 @@
+"""MI355X-native `SeqBasedSWFD`: the class mused imports with `from swfd import SeqBasedSWFD`
+(main.py:10) and drives as
+
+    swfd = SeqBasedSWFD(N=window_size, R=max_norm, d=fused_matrix.shape[1], sketch_dim=reduced_dim)   # :62
+    swfd.fit(row)            # row of shape (1, d), once per row of the window                             # :65-67
+    reduced_matrix, _, _, _ = swfd.get()                                                                   # :70
+
+The reference's implementation is an un-vendored submodule, so the algorithm is
+this repo's specification (oracle/swfd_oracle.py documents it); state and arithmetic live on the
+GPU in libmused_hip (mused_amd/csrc/swfd.hip).  No CPU fallback.
+
+`fit` accepts (b, d) blocks of any b >= 1, NumPy (float/int, e.g. the int64 fused matrix of
+matrix_operations.py:138) or torch tensors (CUDA tensors are appended without a host round trip).
+Host rows are staged and shipped in blocks; the sketch does not depend on the blocking.
+`get()` returns NumPy arrays like the reference; `get_device()` returns CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, F64, I64, call
+from .engine import _require_gpu, ptr, stream_ptr
+
+_DT = {torch.float32: F32, torch.float64: F64, torch.int64: I64}
+
+
+class SeqBasedSWFD:
+    def __init__(self, N, R, d, sketch_dim, *, stage_rows: int = 1024, sweeps: int = 0, device="cuda"):
+        _require_gpu()
+        self.N, self.R, self.d, self.ell = int(N), float(R), int(d), int(sketch_dim)
+        if self.N < 1 or self.d < 1 or self.ell < 1:
+            raise ValueError("N, d and sketch_dim must be positive")
+        self.device = device
+        self._h = C.c_void_p()
+        call("mused_swfd_create", self.N, self.R, self.d, self.ell, int(sweeps), C.byref(self._h))
+        self.L = _lib.lib().mused_swfd_levels(self._h)
+        self._stage = np.empty((max(int(stage_rows), 1), self.d), dtype=np.float64)
+        self._staged = 0
+
+    # -- update ---------------------------------------------------------------------------
+    def _flush(self):
+        if self._staged:
+            t = torch.from_numpy(self._stage[: self._staged]).to(self.device)
+            call("mused_swfd_append", self._h, ptr(t), F64, self._staged, self.d, stream_ptr())
+            # `t` may be released right away: the kernels reading it were enqueued on torch's current
+            # stream, and torch's allocator reuses a block only in stream order.
+            self._staged = 0
+
+    def fit(self, X):
+        if isinstance(X, torch.Tensor) and X.is_cuda:
+            self._flush()
+            t = X if X.dim() == 2 else X.reshape(1, -1)
+            if t.dtype not in _DT:
+                t = t.to(torch.float64)
+            if t.shape[1] != self.d:
+                raise ValueError(f"expected rows of length {self.d}, got {t.shape[1]}")
+            if t.stride(1) != 1:
+                t = t.contiguous()
+            call("mused_swfd_append", self._h, ptr(t), _DT[t.dtype], t.shape[0], t.stride(0), stream_ptr())
+            self._keepalive = t
+            return self
+        a = np.asarray(X)
+        if a.ndim == 1:
+            a = a[None, :]
+        if a.shape[1] != self.d:
+            raise ValueError(f"expected rows of length {self.d}, got {a.shape[1]}")
+        r = 0
+        while r < a.shape[0]:
+            take = min(a.shape[0] - r, self._stage.shape[0] - self._staged)
+            self._stage[self._staged : self._staged + take] = a[r : r + take]
+            self._staged += take
+            r += take
+            if self._staged == self._stage.shape[0]:
+                self._flush()
+        return self
+
+    # -- query ------------------------------------------------------------------------------
+    def get_device(self):
+        """(sketch (l, d), sigma (l,), info (2,) = [level, delta]) as fp64 CUDA tensors."""
+        self._flush()
+        B = torch.empty((self.ell, self.d), dtype=torch.float64, device=self.device)
+        sig = torch.empty(self.ell, dtype=torch.float64, device=self.device)
+        info = torch.empty(2, dtype=torch.float64, device=self.device)
+        call("mused_swfd_query", self._h, ptr(B), ptr(sig), ptr(info), stream_ptr())
+        return B, sig, info
+
+    def get(self):
+        """4-tuple like the reference's get(): (sketch (l, d) float64, singular values of the sketch,
+        level used, delta of the final shrink); main.py:70 consumes element 0 only."""
+        B, sig, info = self.get_device()
+        info = info.cpu().numpy()
+        return B.cpu().numpy(), sig.cpu().numpy(), int(info[0]), float(info[1])
+
+    # -- bookkeeping / multi-GPU state exchange ---------------------------------------------------
+    @property
+    def rows_seen(self) -> int:
+        i, p = C.c_long(), C.c_int()
+        call("mused_swfd_counters", self._h, C.byref(i), C.byref(p))
+        return int(i.value) + self._staged
+
+    def half_bytes(self) -> int:
+        return int(_lib.lib().mused_swfd_half_bytes(self._h))
+
+    def export_half(self, kind: int) -> torch.Tensor:
+        """Pack the MAIN (0) or AUX (1) half of the state into a uint8 CUDA tensor."""
+        self._flush()
+        blob = torch.empty(self.half_bytes(), dtype=torch.uint8, device=self.device)
+        call("mused_swfd_export_half", self._h, int(kind), ptr(blob), stream_ptr())
+        return blob
+
+    def begin_epoch(self, rows_seen: int, main_half: torch.Tensor | None = None):
+        """Start the epoch that begins after `rows_seen` rows (a multiple of N) with MAIN taken from
+        `main_half` (the AUX half of whoever sketched the previous window) and AUX empty."""
+        self._flush()
+        if main_half is not None and main_half.numel() != self.half_bytes():
+            raise ValueError("state blob has the wrong size")
+        call("mused_swfd_begin_epoch", self._h, int(rows_seen), ptr(main_half) if main_half is not None else None,
+             stream_ptr())
+        self._keepalive = main_half
+
+    def close(self):
+        if getattr(self, "_h", None):
+            call("mused_swfd_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,201 @@
+"""GPU parity of the hot path proper: kNN adjacency, fusion, eigenstep and SWFD against the CPU
+oracle and the committed golden vectors (which come from the reference's own modules)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, nbr_hash, regen_inputs
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mused_amd.engine import WindowEngine
+
+    e = WindowEngine(2048)
+    yield e
+    e.close()
+
+
+def _bool_from_adj(adj):
+    m = adj.mask.cpu().numpy().view(np.uint64)
+    bits = np.unpackbits(m.view(np.uint8), axis=1, bitorder="little")
+    return bits[:, : adj.n].astype(bool)
+
+
+WINDOW_CASES = ["c1_gauss_s0", "c1_gauss_s1", "c1_blob_s0", "c1_blob_s1", "c1_fd_s0", "c4s_twomod_s0", "c2m_blob_s0"]
+
+
+@pytest.mark.parametrize("name", WINDOW_CASES)
+def test_window_matches_reference_golden(eng, name):
+    """adjacency hash, fused hash, R, singular values, embedding rows and k-means labels of the
+    reference (golden) reproduced from the device path."""
+    from mused_amd import matrix_operations as mo
+
+    g = load_golden(name)
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    for w in range(n // W):
+        sl = slice(w * W, (w + 1) * W)
+        adjs = [eng.knn_adjacency(torch.from_numpy(m[sl]).cuda(), k, "l2") for m in mods]
+        for a, hh in zip(adjs, g[f"w{w}_adj_hash"]):
+            assert nbr_hash(_bool_from_adj(a)) == str(hh)
+        fused = eng.fuse(adjs)
+        assert nbr_hash(_bool_from_adj(fused)) == str(g[f"w{w}_fused_hash"])
+        assert str(fused.to_dense().cpu().numpy().dtype) == str(g[f"w{w}_fused_dtype"])
+        assert eng.max_row_sq_norm(fused) == pytest.approx(float(g[f"w{w}_R"]), rel=1e-12)
+        emb, sig = eng.svd_reduce(fused, ell, seed, nnz_cap=W * k * len(mods))
+        flags, stats = eng.rsvd_status()
+        assert flags == 0
+        emb, sig = emb.cpu().numpy(), sig.cpu().numpy()
+        np.testing.assert_allclose(sig, g[f"w{w}_sigma"], rtol=1e-9)  # north star: 1e-4 rel
+        rows = g[f"w{w}_emb_rows"]
+        scale = np.abs(g[f"w{w}_emb_sample"]).max()
+        np.testing.assert_allclose(emb[rows], g[f"w{w}_emb_sample"], atol=1e-7 * scale)
+        np.testing.assert_allclose(np.abs(emb).sum(axis=0), g[f"w{w}_emb_abs_colsum"], rtol=1e-7)
+        km = mo.perform_clustering(emb, len(np.unique(labels[sl])), seed)
+        assert np.array_equal(km.astype(np.int32), g[f"w{w}_kmeans_labels"])  # bit-exact event indices
+
+
+def test_cosine_adjacency_matches_oracle(eng):
+    from oracle import mo_oracle as omo
+
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((700, 96)).astype(np.float32)
+    adj = eng.knn_adjacency(torch.from_numpy(X).cuda(), 20, "cosine")
+    ref = omo.create_adjacency_matrix(X, "cosine", 20)
+    assert np.array_equal(_bool_from_adj(adj), ref.astype(bool))
+    assert np.all(ref.sum(1) == 20)
+
+
+def test_rsvd_intermediate_components(eng):
+    """Vt (after svd_flip) and the embedding against the oracle on a two-modality window."""
+    from mused_amd import synth
+    from oracle import mo_oracle as omo
+
+    mods, _ = synth.two_modality_blob_stream(600, 24, 3, n_centres=5)
+    adjs = [eng.knn_adjacency(torch.from_numpy(m).cuda(), 15, "l2") for m in mods]
+    fused = eng.fuse(adjs)
+    F = omo.fuse_matrices([omo.create_adjacency_matrix(m, "", 15) for m in mods])
+    assert np.array_equal(_bool_from_adj(fused), F.astype(bool))
+    emb, sig, comp = eng.svd_reduce(fused, 12, 7, want_components=True)
+    e_ref, s_ref, vt_ref = omo.randomized_svd_reduce(F, 12, 7)
+    np.testing.assert_allclose(sig.cpu().numpy(), s_ref, rtol=1e-10)
+    np.testing.assert_allclose(comp.cpu().numpy(), vt_ref.T, atol=1e-8)
+    np.testing.assert_allclose(emb.cpu().numpy(), e_ref, atol=1e-8 * np.abs(e_ref).max())
+
+
+def test_rsvd_tiny_window_more_random_columns_than_rows(eng):
+    """main.py:318-324 demo sizes: n_components + 10 > n."""
+    g = load_golden("edges")
+    from mused_amd import matrix_operations as mo
+
+    A = mo.create_adjacency_matrix(g["demo_X"], "", 3)
+    assert np.array_equal(A.astype(np.uint8), g["demo_A"])
+    emb = mo.perform_svd_reduction(mo.fuse_matrices([A]), 2, 0)
+    np.testing.assert_allclose(emb, g["demo_emb"], atol=1e-9)
+
+
+# ---------------------------------------------------------------- SWFD -------------------
+def _swfd_pair(N, R, d, ell):
+    from mused_amd.swfd import SeqBasedSWFD as Dev
+    from oracle.swfd_oracle import SeqBasedSWFD as Ora
+
+    return Dev(N=N, R=R, d=d, sketch_dim=ell), Ora(N=N, R=R, d=d, sketch_dim=ell)
+
+
+def _compare(dev, ora, tag):
+    Bd, sd, ld, dd = dev.get()
+    Bo, so, lo, do = ora.get()
+    assert ld == lo, f"{tag}: level {ld} vs {lo}"
+    s0 = max(so[0], 1e-300)
+    np.testing.assert_allclose(sd, so, rtol=0, atol=1e-8 * s0, err_msg=tag)  # north star: 1e-4 rel
+    big = so > 1e-3 * s0
+    np.testing.assert_allclose(sd[big], so[big], rtol=1e-6, err_msg=tag)
+    np.testing.assert_allclose(Bd.T @ Bd, Bo.T @ Bo, rtol=0, atol=1e-8 * s0 * s0, err_msg=tag)
+    assert abs(dd - do) <= 1e-8 * s0 * s0
+
+
+@pytest.mark.parametrize("kind", ["gauss", "blob", "fd"])
+def test_swfd_matches_oracle_over_a_stream(kind):
+    from mused_amd import synth
+
+    N, ell, d = 400, 8, 40
+    X, _ = synth.make_stream(kind, 3 * N + 37, d, 3)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    dev, ora = _swfd_pair(N, R, d, ell)
+    assert dev.L == ora.L
+    t = 0
+    for step in [1, 7, 120, 272, 1, 399, 400, 37]:  # ragged batching incl. epoch boundaries
+        blk = X[t : t + step]
+        dev.fit(blk)
+        ora.fit(blk)
+        t += step
+        _compare(dev, ora, f"{kind} t={t}")
+    dev.close()
+
+
+def test_swfd_device_rows_int64_and_per_row_fit():
+    """mused wiring: d = window size, rows of the int64 fused adjacency, one fit() per row (main.py:65-67)."""
+    W, ell = 96, 6
+    rng = np.random.default_rng(2)
+    fused = (rng.random((2 * W, W)) < 0.08).astype(np.int64)
+    R = float(np.max(np.linalg.norm(fused[:W], axis=1) ** 2))
+    dev, ora = _swfd_pair(W, R, W, ell)
+    for r in range(W):
+        row = fused[r, :].reshape(1, -1)
+        dev.fit(row)
+        ora.fit(row)
+    _compare(dev, ora, "per-row window 1")
+    dev.fit(torch.from_numpy(fused[W:]).cuda())  # device-resident int64 block
+    ora.fit(fused[W:])
+    _compare(dev, ora, "device block window 2")
+    red = dev.get()[0]
+    assert red.shape == (ell, W) and red.T.shape == (W, ell)  # main.py:73-76 transposes this
+    dev.close()
+
+
+def test_swfd_expiry_and_dumps():
+    """A heavy early direction forces dumps on the low levels and must be forgotten N rows later."""
+    N, ell, d = 300, 6, 24
+    rng = np.random.default_rng(0)
+    heavy = np.zeros((N, d))
+    heavy[:, 0] = 30.0 * (1 + 0.1 * rng.standard_normal(N))
+    X = np.vstack([heavy, rng.standard_normal((2 * N + 11, d))])
+    R = float((X**2).sum(1).max())
+    dev, ora = _swfd_pair(N, R, d, ell)
+    for t0 in range(0, len(X), 100):
+        dev.fit(X[t0 : t0 + 100])
+        ora.fit(X[t0 : t0 + 100])
+        _compare(dev, ora, f"t={t0 + 100}")
+    B = dev.get()[0]
+    assert (B[:, 0] ** 2).sum() < 5 * N
+    dev.close()
+
+
+def test_swfd_state_exchange_between_ranks():
+    """Windows sharded over two sketch objects (ranks): rank 1 starts window 1 from the AUX half of
+    rank 0 and must equal the single sequential sketch."""
+    from mused_amd import synth
+    from mused_amd.swfd import SeqBasedSWFD as Dev
+
+    N, ell, d = 256, 8, 32
+    X, _ = synth.blob_stream(2 * N, d, 5, n_centres=3)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    seq = Dev(N=N, R=R, d=d, sketch_dim=ell)
+    seq.fit(X)
+    B_seq, s_seq, l_seq, _ = seq.get()
+    r0 = Dev(N=N, R=R, d=d, sketch_dim=ell)
+    r0.fit(X[:N])
+    blob = r0.export_half(1)
+    r1 = Dev(N=N, R=R, d=d, sketch_dim=ell)
+    r1.begin_epoch(N, blob)
+    r1.fit(X[N:])
+    B1, s1, l1, _ = r1.get()
+    assert l1 == l_seq
+    assert np.array_equal(s1, s_seq) and np.array_equal(B1, B_seq)
+    for o in (seq, r0, r1):
+        o.close()
