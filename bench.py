@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stream rows/s (+ p50 per-window latency) of the MI355X hot path on the
+BASELINE.json config-2 workload: synthetic stream, d = 1024, l = 128, window W = N = 10,000, k = 50.
+
+One STEP = one window of W rows, already resident in HBM, through the whole path:
+    SeqBasedSWFD over the W feature rows (append + get)         [a5-a7]
+    Euclidean kNN adjacency of the window (fp64 MFMA scores + exact selection)   [a1]
+    fusion / R                                                  [a3, a4]
+    randomized-SVD eigenstep on the fused adjacency             [a8]
+    k-means + Hungarian matching on the host (sklearn / SciPy)  [a10]  -> event labels
+`value` = rows of all ranks / wall time of the K timed steps (max over ranks), inputs resident.
+
+    python bench.py                       # 1 GPU, K = 5, W = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: every rank owns a contiguous block of windows of the stream (mused_amd/distributed.py):
+weak scaling, no data-path collective; one all-gather of raw labels at the end.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration `metric` is quoted on
+    "c2": dict(W=10000, d=1024, ell=128, k=50, name="synthetic d=1024 l=128 window=10000 k=50 (BASELINE config 2)"),
+    # small plumbing case (configs[0] shapes) for quick checks
+    "c1": dict(W=500, d=64, ell=16, k=50, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--kind", default="blob", choices=["blob", "gauss", "fd"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
+    return ap.parse_args()
+
+
+def hip_event_ms(fn, stream, reps=1):
+    """Average duration (ms) of fn() measured with HIP events recorded on `stream`
+    (the stream the kernels are launched on)."""
+    import torch
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def stage_profile(cfg, X, pipe):
+    """Per-stage device times (ms, HIP events on the launch stream) for one resident window, plus
+    the live roofline measurement of the dominant kernels."""
+    import ctypes as C
+
+    import torch
+
+    from mused_amd import _lib
+    from mused_amd.engine import ptr, stream_ptr
+
+    W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
+    eng = pipe.eng
+    st = torch.cuda.current_stream()
+    out = {}
+    # similarity GEMM alone: row norms + fp64 MFMA X X^T with the distance epilogue
+    dt = _lib.F32 if X.dtype == torch.float32 else _lib.F64
+    f_scores = lambda: _lib.call("mused_pairwise_scores", ptr(X), dt, W, d, X.stride(0), 0, ptr(eng.norms),
+                                 ptr(eng.scores), stream_ptr())
+    f_scores()
+    out["scores_gemm_ms"] = hip_event_ms(f_scores, st, 3)
+    w = (W + 63) // 64
+    mask = torch.empty((W, w), dtype=torch.int64, device="cuda")
+    f_sel = lambda: _lib.call("mused_select_k_smallest", ptr(eng.scores), W, W, k, None, ptr(mask), w, stream_ptr())
+    f_sel()
+    out["select_ms"] = hip_event_ms(f_sel, st, 3)
+    adj = eng.knn_adjacency(X, k)
+    f_rsvd = lambda: eng.svd_reduce(adj, ell, pipe.seed, nnz_cap=W * k)
+    f_rsvd()
+    out["rsvd_ms"] = hip_event_ms(f_rsvd, st, 2)
+    if pipe.fswfd is not None:
+        sk = pipe.fswfd
+        f_app = lambda: sk.fit(X)
+        out["swfd_append_ms"] = hip_event_ms(f_app, st, 1)
+        f_get = lambda: sk.get_device()
+        out["swfd_query_ms"] = hip_event_ms(f_get, st, 1)
+        out["swfd_levels"] = sk.L
+    return out
+
+
+def cpu_baseline(cfg, kind, seed, with_swfd=True):
+    """The CPU oracle (oracle/*.py, a port of the reference path pinned to its golden vectors) timed
+    on this box's host cores over a bounded sample of the same workload."""
+    import multiprocessing
+
+    from mused_amd import synth
+    from oracle import mo_oracle as omo
+    from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
+
+    W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
+    X, labels = synth.stream_window(kind, 0, W, d, seed)
+    t0 = time.perf_counter()
+    A = omo.create_adjacency_matrix(X.astype(np.float64), "", k)
+    F = omo.fuse_matrices([A])
+    omo.max_row_sq_norm(F)
+    t1 = time.perf_counter()
+    emb, _, _ = omo.randomized_svd_reduce(F, ell, seed)
+    t2 = time.perf_counter()
+    omo.perform_clustering(emb, len(np.unique(labels)), seed)
+    t3 = time.perf_counter()
+    swfd_rows = 0
+    t_swfd_per_row = 0.0
+    if with_swfd:
+        X64 = X.astype(np.float64)
+        R = float((X64**2).sum(1).max())
+        sk = OraSWFD(N=W, R=R, d=d, sketch_dim=ell)
+        swfd_rows = min(W, 4 * ell)  # 4 rotations of every level; steady-state cost per row is constant
+        ts = time.perf_counter()
+        sk.fit(X64[:swfd_rows])
+        sk.get()
+        t_swfd_per_row = (time.perf_counter() - ts) / swfd_rows
+    window_s = (t3 - t0) + t_swfd_per_row * W
+    return {
+        "value": W / window_s,
+        "unit": "rows/s",
+        "cores": multiprocessing.cpu_count(),
+        "kind": "port",
+        "sample": f"1 window of {W} rows through oracle adjacency+fuse ({t1 - t0:.2f}s), eigenstep ({t2 - t1:.2f}s), "
+                  f"k-means ({t3 - t2:.2f}s); SWFD oracle timed on {swfd_rows} rows "
+                  f"({t_swfd_per_row * 1e3:.2f} ms/row) and extrapolated to the window; default BLAS threading",
+        "window_seconds": window_s,
+    }
+
+
+def main():
+    args = parse()
+    cfg = dict(WORKLOADS[args.workload])
+    W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from mused_amd import distributed as mdist
+    from mused_amd import matrix_operations as mo
+    from mused_amd import synth
+    from mused_amd.pipeline import StreamPipeline
+
+    K, Wu = args.steps, args.warmup
+    per_rank = K + Wu
+    first = rank * per_rank  # contiguous block of the global stream; its warm-up windows are the SWFD halo
+    host = [synth.stream_window(args.kind, first + t, W, d, args.seed) for t in range(per_rank)]
+    rows = [torch.from_numpy(x).cuda() for x, _ in host]  # inputs resident in HBM before timing
+    labels = [l for _, l in host]
+
+    pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=not args.no_swfd, async_labels=True)
+    if not args.no_swfd:
+        # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
+        from mused_amd.swfd import SeqBasedSWFD
+
+        R0 = float((rows[0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
+        R = mdist.broadcast_scalar(R0, 0, device="cuda") if world > 1 else R0
+        pipe.fswfd = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell)
+
+    for t in range(Wu):
+        pipe.process_window([rows[t]], labels[t], trigger=(first + t + 1) * W - 1)
+    pipe.flush()
+    n_warm_lat = len(pipe.latencies)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(Wu, per_rank):
+        pipe.process_window([rows[t]], labels[t], trigger=(first + t + 1) * W - 1)
+    pipe.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # label chain across ranks (outside the timed region: W ints per window)
+    raw_local = np.array([tr["raw"] for tr in pipe.trace[Wu:]], dtype=np.int64)
+    counts = [K] * world
+    raw_all = mdist.gather_raw_labels(raw_local, counts, device="cuda")
+    all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
+
+    if rank == 0:
+        lat = np.array(pipe.latencies[n_warm_lat:])
+        stages = stage_profile(cfg, rows[-1], pipe)
+        # ---- roofline of the dominant kernel (measured live with HIP events above) ----
+        flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
+        gemm_s = stages["scores_gemm_ms"] * 1e-3
+        roof = {
+            "kernel": "gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64)",
+            "bound": "mfma",
+            "achieved": flops / gemm_s / 1e12,
+            "peak": 78.6,
+            "unit": "TFLOP/s",
+            "frac": flops / gemm_s / 1e12 / 78.6,
+            "traffic": None,
+            "launch_ms": stages["scores_gemm_ms"],
+            "algorithmic_flops_per_launch": flops,
+        }
+        res = {
+            "metric": "stream rows/sec, d=1024 l=128 window=10k synthetic (SWFD + kNN similarity + eigenstep + labels)",
+            "value": world * K * W / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wu,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": cfg["name"],
+                "stream": args.kind,
+                "W": W, "d": d, "l": ell, "k": k, "modalities": 1,
+                "swfd_levels": stages.get("swfd_levels"),
+                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s)",
+                "labels_sha16": __import__("hashlib").sha256(all_labels.astype(np.int64).tobytes()).hexdigest()[:16],
+            },
+            "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
+            "stages_ms": stages,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.kind, args.seed, with_swfd=not args.no_swfd)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    pipe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+"""Window loop of the streaming pipeline (the role of `process_streaming_data`, main.py:13-130),
+built on the device engine.
+
+Per full window (trigger rule of main.py:32):
+    per-modality kNN adjacency (device bitmask)  ->  OR-fusion  ->
+        approach "sSVDMC"/"sSVDMC_hung": randomized-SVD embedding            (main.py:79)
+        approach "SWFDMC"             : SeqBasedSWFD over the rows of the fused matrix, R from the
+                                        first window only, sketch transposed to (W, l)  (main.py:58-76)
+    -> k-means with n_clusters = #distinct true labels in the window (main.py:41,97)
+    -> Hungarian matching against the previous window, min_overlap = 3 (main.py:110)
+    -> labels appended (main.py:118-119).
+
+Device work of window t+1 is enqueued while the host runs k-means / matching of window t
+(`async_labels=True`): the embedding is copied to pinned memory behind an event, a worker thread
+waits on the event and runs the scikit-learn / SciPy consumers in window order.
+"""
+from __future__ import annotations
+
+import time
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import matrix_operations as mo
+from .engine import WindowEngine
+from .swfd import SeqBasedSWFD
+
+
+class StreamPipeline:
+    def __init__(self, window_size, reduced_dim, k_basis, seed, approach="sSVDMC", modality_types=None,
+                 step_window_ratio=1, engine=None, async_labels=True, feature_sketch=False):
+        if approach not in ("sSVDMC", "sSVDMC_hung", "SWFDMC"):
+            raise ValueError(f"approach {approach!r} is not on the device hot path")
+        self.W, self.ell, self.k, self.seed = int(window_size), int(reduced_dim), int(k_basis), int(seed)
+        self.approach = approach
+        self.types = modality_types
+        self.ratio = step_window_ratio
+        self.eng = engine or WindowEngine(self.W)
+        self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)
+        self.feature_sketch = feature_sketch
+        self.fswfd = None         # optional SWFD over the raw feature rows (BASELINE config 2 wording)
+        self.prev = None
+        self.out = []
+        self.trace = []
+        self.latencies = []
+        self._pool = ThreadPoolExecutor(max_workers=1) if async_labels else None
+        self._pending = deque()
+
+    # ---- device side of one window --------------------------------------------------------------
+    def window_device(self, mods):
+        """mods: list of (W, d_m) float32/float64 tensors on the device.  Returns (reduced (W, m) CUDA
+        tensor, sigma CUDA tensor)."""
+        types = self.types or [""] * len(mods)
+        adjs = [self.eng.knn_adjacency(m, self.k, mo._metric_for(t)) for m, t in zip(mods, types)]
+        fused = self.eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
+        if len(adjs) == 1:
+            fused.fused = False
+        if self.feature_sketch:
+            X = mods[0] if len(mods) == 1 else torch.cat(mods, dim=1)
+            if self.fswfd is None:
+                R = float((X.double() ** 2).sum(dim=1).max().item())
+                self.fswfd = SeqBasedSWFD(N=self.W, R=R, d=X.shape[1], sketch_dim=self.ell)
+            self.fswfd.fit(X)
+            self.feature_B, self.feature_sigma, _ = self.fswfd.get_device()
+        if self.approach == "SWFDMC":
+            if self.swfd is None:  # main.py:60-62
+                R = self.eng.max_row_sq_norm(fused)
+                self.swfd = SeqBasedSWFD(N=self.W, R=R, d=fused.n, sketch_dim=self.ell)
+            self.swfd.fit(fused.to_dense())  # rows of the fused matrix, int64 for >= 2 modalities
+            B, sigma, _ = self.swfd.get_device()
+            reduced = B.t().contiguous() if B.shape[0] != self.W else B  # main.py:73-76
+            return reduced, sigma
+        nnz_cap = fused.n * max(self.k, 1) * len(adjs)
+        emb, sigma = self.eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap)
+        return emb, sigma
+
+    # ---- host consumers -------------------------------------------------------------------------
+    def _labels(self, reduced_host, n_clusters, trigger, sigma_host, t_start):
+        clusters = mo.perform_clustering(reduced_host, n_clusters, self.seed)
+        matched = mo.match_clusters(self.prev, clusters, method="hungarian", min_overlap=3)
+        if matched is None or len(matched) == 0:  # main.py:114-116
+            matched = np.full(self.W, 0)
+        self.prev = matched
+        self.out.extend(matched)
+        self.trace.append(dict(trigger=trigger, sigma=sigma_host, raw=np.asarray(clusters), matched=np.asarray(matched)))
+        self.latencies.append(time.perf_counter() - t_start)
+
+    def _finish(self, job):
+        ev, red_pin, sig_pin, n_clusters, trigger, t_start = job
+        ev.synchronize()
+        self._labels(red_pin.numpy(), n_clusters, trigger, sig_pin.numpy().copy(), t_start)
+
+    def process_window(self, mods, true_labels_window, trigger=None):
+        t_start = time.perf_counter()
+        n_clusters = len(np.unique(true_labels_window))  # main.py:41
+        reduced, sigma = self.window_device(mods)
+        red_pin = torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True)
+        sig_pin = torch.empty(sigma.shape, dtype=sigma.dtype, pin_memory=True)
+        red_pin.copy_(reduced, non_blocking=True)
+        sig_pin.copy_(sigma, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start)
+        if self._pool is None:
+            self._finish(job)
+        else:
+            self._pending.append(self._pool.submit(self._finish, job))
+
+    def flush(self):
+        while self._pending:
+            self._pending.popleft().result()
+
+    def run(self, data_modalities, true_labels):
+        """Stream whole modalities (host or device arrays) through the window loop; returns the
+        concatenated event labels (`all_clusters`, main.py:125)."""
+        dev = [m if isinstance(m, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(m)) for m in data_modalities]
+        dev = [m.cuda() for m in dev]
+        n = dev[0].shape[0]
+        for i in range(n):
+            if i + 1 >= self.W and (i + 1) * self.ratio % self.W == 0:  # main.py:32
+                lo = i + 1 - self.W
+                self.process_window([m[lo : i + 1] for m in dev], true_labels[lo : i + 1], trigger=i)
+        self.flush()
+        return np.array(self.out)
+
+    def close(self):
+        self.flush()
+        if self._pool is not None:
+            self._pool.shutdown()
+        for s in (self.swfd, self.fswfd):
+            if s is not None:
+                s.close()
+
+
+def process_streaming_data(results, data_modalities, modality_types, window_size, reduced_dim, k_basis, n_clusters_total,
+                           seed, approach, complete_true_labels, step_window_ratio, noise_rate, label_mode, sorting,
+                           eps, min_samples):
+    """Same positional parameters as main.py:13.  The reference hands its outputs to
+    metrics_evaluation (out of scope here); this returns `results` with the label arrays and the
+    wall time instead."""
+    t0 = time.time_ns()
+    types = [t if t in ("cosine",) else "" for t in modality_types]
+    pipe = StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, types, step_window_ratio)
+    clusters = pipe.run(data_modalities, np.asarray(complete_true_labels))
+    pipe.close()
+    results = dict(results or {})
+    results["all_clusters"] = clusters
+    results["processing_time"] = (time.time_ns() - t0) / 1e9
+    return results

@@ -70,3 +70,25 @@ def array_digest(a: np.ndarray) -> str:
     h.update(str(a.shape).encode())
     h.update(a.tobytes())
     return h.hexdigest()
+
+
+def stream_window(kind: str, window_index: int, W: int, d: int, seed: int = 0, n_centres: int = 8, sep: float = 2.0):
+    """Window `window_index` of an unbounded stream, generated independently of the others (so ranks
+    can materialise only their own windows).  Centres / mixing matrices depend on `seed` only; rows on
+    (seed, window_index).  Returns (rows float32 (W, d), labels int64 (W,))."""
+    base = np.random.default_rng([seed, 0x5EED])
+    rng = np.random.default_rng([seed, 1 + window_index])
+    if kind == "gauss":
+        return rng.standard_normal((W, d), dtype=np.float32), rng.integers(0, 4, size=W).astype(np.int64)
+    if kind == "blob":
+        centres = (sep * base.standard_normal((n_centres, d))).astype(np.float32)
+        labels = rng.integers(0, n_centres, size=W)
+        X = centres[labels] + rng.standard_normal((W, d), dtype=np.float32)
+        return X.astype(np.float32), labels.astype(np.int64)
+    if kind == "fd":
+        m, zeta = 10, 10.0
+        U, _ = np.linalg.qr(base.standard_normal((d, m)))
+        D = np.diag(1.0 - np.arange(m) / m)
+        A = rng.standard_normal((W, m)) @ D @ U.T + rng.standard_normal((W, d)) / zeta
+        return A.astype(np.float32), np.zeros(W, dtype=np.int64)
+    raise ValueError(kind)
