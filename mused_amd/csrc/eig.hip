@@ -21,6 +21,10 @@ namespace mused {
 
 struct EigPlan {
   int n, batch, sweeps;
+  int method;  // 0 = two-sided, one launch per rotation set; 1 = one-sided block Jacobi (default)
+  int ldn;     // OSJ: padded order (multiple of 64) = threads per workgroup
+  double* Gc;  // OSJ: batch x ldn x ldn, column-major working copy
+  double* lam; // OSJ: batch x ldn column norms
   double* G[2];
   double* V[2];
   hipGraph_t graph;
@@ -134,6 +138,351 @@ __global__ void eig_extract_kernel(const double* __restrict__ G, const double* _
   if (r == c) evals[(gid / ((long)n * n)) * n + r] = G[gid];
 }
 
+
+// ======================= one-sided block Jacobi (register resident) =========================
+// For a symmetric PSD G = U diag(lam) U^T, orthogonalising the COLUMNS of G by plane rotations
+// (Hestenes) ends with columns w_j = lam_j u_j: eigenvalues are the column norms, eigenvectors the
+// normalised columns -- no eigenvector accumulation.  Columns are grouped in blocks of CB; one
+// workgroup owns a PAIR of blocks for one round (round-robin over block pairs: nb - 1 launches per
+// sweep, nb / 2 independent workgroups per matrix and launch).  Thread r keeps ROW r of the 2 CB
+// columns in registers (2 CB doubles), runs one full round-robin sweep over those columns with a
+// compile-time pairing schedule (register indices are constants), and needs only the CB dot
+// products of each step reduced across the workgroup (in-wave transpose-reduce + one LDS hop).
+// Column norms are carried in LDS and updated from the rotation, so each step reduces CB values.
+constexpr int OSJ_CB = 16;
+
+__host__ __device__ constexpr int osj_pair_p(int m2, int step, int k) {
+  // round robin on m2 (even) players; returns the smaller index of pair k at `step`
+  const int m = m2 - 1;
+  const int a = (k == 0) ? m : (step + k) % m;
+  const int b = (k == 0) ? (step % m) : ((step - k + m) % m);
+  return a < b ? a : b;
+}
+__host__ __device__ constexpr int osj_pair_q(int m2, int step, int k) {
+  const int m = m2 - 1;
+  const int a = (k == 0) ? m : (step + k) % m;
+  const int b = (k == 0) ? (step % m) : ((step - k + m) % m);
+  return a < b ? b : a;
+}
+
+// Sum N values (N = 8, 16, 32) over the 64 lanes of a wave with N - 1 + (6 - log2 N) shuffles: each
+// halving stage exchanges half of the values with the lane `mask` away.  On return v[0] of lane l is
+// the wave total of value `idx` (lanes that share idx hold the same total).
+// ---- wave-level "transpose reduce": N values per lane summed over the 64 lanes --------------------
+// Stage partners (all VALU, no LDS crossbar): l^32 by v_permlane32_swap, l^16 by v_permlane16_swap
+// (both exchange a kept and a sent value in one instruction, no selects), then row_mirror (flips bit
+// 3), row_half_mirror (flips bit 2), quad_perm xor 2, xor 1 through DPP moves.  While more than one
+// value is left a stage halves the count: lanes with the stage bit set keep the upper half of the
+// values, the others the lower half.  On return lane l holds the wave total of value
+// idx = (bits 5, 4, 3, 2[, 1] of l, as many as there were halving stages); lanes sharing idx agree.
+__device__ __forceinline__ double f64_from_parts(unsigned lo, unsigned hi) {
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return f64_from_parts((unsigned)lo, (unsigned)hi);
+}
+// a <- a(l) + a(l ^ 32) on lanes 0-31, b(l) + b(l ^ 32) on lanes 32-63 (a = kept-by-low, b = kept-by-high)
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  auto rl = __builtin_amdgcn_permlane32_swap((unsigned)(ua & 0xffffffffull), (unsigned)(ub & 0xffffffffull), false, false);
+  auto rh = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  return f64_from_parts(rl[0], rh[0]) + f64_from_parts(rl[1], rh[1]);
+}
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  auto rl = __builtin_amdgcn_permlane16_swap((unsigned)(ua & 0xffffffffull), (unsigned)(ub & 0xffffffffull), false, false);
+  auto rh = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  return f64_from_parts(rl[0], rh[0]) + f64_from_parts(rl[1], rh[1]);
+}
+constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR2 = 0x4E, DPP_QUAD_XOR1 = 0xB1;
+
+template <int N>
+__device__ __forceinline__ double wave_treduce(double (&v)[N], int lane, int& idx) {
+  static_assert(N == 8 || N == 16 || N == 32, "wave_treduce: N must be 8, 16 or 32");
+  // stage 1: l ^ 32 (N -> N/2)
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) v[i] = swap32_add(v[i], v[i + N / 2]);
+  // stage 2: l ^ 16 (N/2 -> N/4)
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) v[i] = swap16_add(v[i], v[i + N / 4]);
+  // stage 3: row mirror, decided by bit 3 (N/4 -> N/8)
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      const double keep = hi ? v[i + N / 8] : v[i];
+      const double send = hi ? v[i] : v[i + N / 8];
+      v[i] = keep + dpp_mov_f64<DPP_ROW_MIRROR>(send);
+    }
+  }
+  int id = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+  double t;
+  if constexpr (N >= 16) {  // stage 4: half mirror, decided by bit 2 (N/8 -> N/16)
+    const bool hi = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 16; ++i) {
+      const double keep = hi ? v[i + N / 16] : v[i];
+      const double send = hi ? v[i] : v[i + N / 16];
+      v[i] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+    }
+    id = id * 2 + ((lane >> 2) & 1);
+    if constexpr (N == 32) {  // stage 5: xor 2, decided by bit 1 (2 -> 1)
+      const bool h2 = (lane & 2) != 0;
+      const double keep = h2 ? v[1] : v[0];
+      const double send = h2 ? v[0] : v[1];
+      t = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send);
+      id = id * 2 + ((lane >> 1) & 1);
+    } else {
+      t = v[0] + dpp_mov_f64<DPP_QUAD_XOR2>(v[0]);
+    }
+  } else {
+    t = v[0] + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(v[0]);
+    t = t + dpp_mov_f64<DPP_QUAD_XOR2>(t);
+  }
+  t = t + dpp_mov_f64<DPP_QUAD_XOR1>(t);
+  idx = id;
+  return t;
+}
+
+__device__ __forceinline__ double osj_readlane(double v, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), l);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Plane rotation that zeroes the inner product pq of two columns with squared norms pp, qq:
+//   zeta = (qq - pp) / (2 pq),  t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),  c = 1/sqrt(1 + t^2),  s = t c.
+// One fp64 divide and one fp64 sqrt; the two reciprocals are fp32 hardware seeds refined by Newton
+// steps in fp64 (full fp64 accuracy matters: an angle error d leaves d * sqrt(pp / qq) of cosine
+// between a large and a small column, which stalls convergence on graded spectra).
+__device__ __forceinline__ void osj_rotation(double pp, double qq, double pq, double& c, double& s, double& npp,
+                                             double& nqq) {
+  c = 1.0; s = 0.0; npp = pp; nqq = qq;
+  if (pq * pq > 1e-30 * (pp * qq) && pq != 0.0) {
+    const double zeta = (qq - pp) / (2.0 * pq);
+    const double az = fabs(zeta);
+    double t;
+    if (az > 1e100) {
+      t = 0.5 / zeta;
+    } else {
+      const double y = az + sqrt(1.0 + az * az);  // >= 1
+      double r = (double)(1.0f / (float)y);       // 0 if y overflows fp32: t = 0, rotation skipped this time
+      r = r * (2.0 - y * r);
+      r = r * (2.0 - y * r);
+      t = zeta < 0.0 ? -r : r;
+    }
+    const double h = 1.0 + t * t;  // in [1, 2]
+    double c0 = (double)rsqrtf((float)h);
+    c0 = c0 * (1.5 - 0.5 * h * c0 * c0);
+    c0 = c0 * (1.5 - 0.5 * h * c0 * c0);
+    c = c0;
+    s = t * c0;
+    npp = pp - t * pq;
+    nqq = qq + t * pq;
+  }
+}
+
+// Pairing schedules of the columns held by one workgroup (compile-time: register indices are constants).
+//   CROSS = false: round robin over all C2 columns (C2 - 1 steps of C2 / 2 pairs): every pair once.
+//   CROSS = true : only pairs (i, CB + (i + step) % CB) between the two blocks (CB steps of CB pairs);
+//                  pairs inside a block are rotated once per sweep by the INTRA launch instead, so a
+//                  sweep touches every pair of the matrix exactly once (n - 1 dependent steps).
+template <bool CROSS>
+__host__ __device__ constexpr int osj_sched_p(int c2, int step, int k) {
+  return CROSS ? k : osj_pair_p(c2, step, k);
+}
+template <bool CROSS>
+__host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
+  return CROSS ? (c2 / 2 + (k + step) % (c2 / 2)) : osj_pair_q(c2, step, k);
+}
+
+template <int CB, int NT, int MODE>
+__global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
+                                                      double* __restrict__ conv) {
+  // MODE 0: block pair, all pairs; MODE 1: block pair, cross pairs only; MODE 2: ONE block of 2*CB
+  // consecutive columns (blockIdx.x), all pairs inside it.
+  constexpr bool CROSS = (MODE == 1);
+  constexpr int C2 = 2 * CB;
+  constexpr int NSTEP = CROSS ? CB : C2 - 1;
+  constexpr int NW = NT / 64;
+  __shared__ double part[2][NW][C2];  // double-buffered cross-wave partial sums
+  __shared__ double nrm[NW][C2];      // per-wave private copy of the squared column norms
+  __shared__ double4 csw[NW][CB];     // per-wave 2x2 orthogonal maps of the step's CB pairs
+
+  double* M = Gc + (long)blockIdx.y * ldn * ldn;
+  int bp, bq;
+  if (MODE == 2) {
+    bp = 2 * blockIdx.x;
+    bq = bp + 1;
+  } else {
+    const int k = blockIdx.x, m = nb - 1;
+    int a = (k == 0) ? m : (round + k) % m;
+    int b = (k == 0) ? (round % m) : ((round - k + m) % m);
+    bp = a < b ? a : b;
+    bq = a < b ? b : a;
+  }
+  const int r = threadIdx.x, lane = r & 63, wave = r >> 6;
+  double x[C2];
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    x[j] = M[(long)(bp * CB + j) * ldn + r];
+    x[CB + j] = M[(long)(bq * CB + j) * ldn + r];
+  }
+  // squared column norms (every wave ends up with its own full copy)
+  {
+    double sq[C2];
+#pragma unroll
+    for (int j = 0; j < C2; ++j) sq[j] = x[j] * x[j];
+    int idx;
+    const double t = wave_treduce<C2>(sq, lane, idx);
+    if ((lane & ((64 / C2) - 1)) == 0) part[1][wave][idx] = t;
+    __syncthreads();
+    if (lane < C2) {
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sum += part[1][w][lane];
+      nrm[wave][lane] = sum;
+    }
+    // part[1] is next written at step 1, after the barrier of step 0: no hazard
+  }
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int buf = step & 1;
+    double dv[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) dv[k] = x[osj_sched_p<CROSS>(C2, step, k)] * x[osj_sched_q<CROSS>(C2, step, k)];
+    int idx;
+    const double t = wave_treduce<CB>(dv, lane, idx);
+    if ((lane & ((64 / CB) - 1)) == 0) part[buf][wave][idx] = t;
+    __syncthreads();
+    double c = 1.0, s = 0.0;
+    if (lane < CB) {  // every wave computes all CB rotations redundantly: no second barrier
+      double pq = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) pq += part[buf][w][lane];
+      int p, q;
+      if (CROSS) {
+        p = lane;
+        q = CB + (lane + step) % CB;
+      } else {
+        const int m = C2 - 1;
+        const int a = (lane == 0) ? m : (step + lane) % m;
+        const int b = (lane == 0) ? (step % m) : ((step - lane + m) % m);
+        p = a < b ? a : b;
+        q = a < b ? b : a;
+      }
+      double npp, nqq;
+      osj_rotation(nrm[wave][p], nrm[wave][q], pq, c, s, npp, nqq);
+      // de Rijk: keep the larger column in the lower position (a reflection instead of a rotation
+      // when the norms come out in the wrong order) -- speeds convergence on graded spectra
+      const bool sw = npp < nqq;
+      nrm[wave][p] = sw ? nqq : npp;
+      nrm[wave][q] = sw ? npp : nqq;
+      csw[wave][lane] = sw ? make_double4(s, c, c, -s) : make_double4(c, -s, s, c);
+    }
+    // same wave wrote csw: program order + the compiler's lgkmcnt wait make it visible (no barrier)
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+      const double4 m4 = csw[wave][k];
+      const int p = osj_sched_p<CROSS>(C2, step, k), q = osj_sched_q<CROSS>(C2, step, k);
+      const double xp = x[p], xq = x[q];
+      x[p] = m4.x * xp + m4.y * xq;
+      x[q] = m4.z * xp + m4.w * xq;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    M[(long)(bp * CB + j) * ldn + r] = x[j];
+    M[(long)(bq * CB + j) * ldn + r] = x[CB + j];
+  }
+  (void)conv;
+  (void)n;
+}
+
+// G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
+__global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, double* __restrict__ Gc) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)ldn * ldn;
+  if (gid >= per * gridDim.y) return;
+  const int b = blockIdx.y;
+  const long e = gid;
+  if (e >= per) return;
+  const int c = (int)(e / ldn), r = (int)(e - (long)c * ldn);
+  Gc[b * per + e] = (c < n && r < n) ? G[(long)b * n * n + (long)c * n + r] : 0.0;
+}
+
+// lam[b][j] = |column j| ; one wave per column
+__global__ void osj_norms_kernel(const double* __restrict__ Gc, int ldn, double* __restrict__ lam) {
+  const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (col >= ldn) return;
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const double* c = Gc + ((long)b * ldn + col) * ldn;
+  double s = 0.0;
+  for (int r = lane; r < ldn; r += 64) s += c[r] * c[r];
+  s = wave_sum(s);
+  if (lane == 0) lam[(long)b * ldn + col] = sqrt(s);
+}
+
+// evals (batch x n) and V (batch x n x n row-major, column j = eigenvector j)
+__global__ void osj_extract_kernel(const double* __restrict__ Gc, const double* __restrict__ lam, int n, int ldn,
+                                   double* __restrict__ evals, double* __restrict__ V) {
+  const int b = blockIdx.y;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * n) return;
+  const int j = (int)(gid / n), a = (int)(gid - (long)j * n);  // consecutive threads: consecutive rows of column j
+  const double l = lam[(long)b * ldn + j];
+  if (a == 0) evals[(long)b * n + j] = l;
+  if (V) V[(long)b * n * n + (long)a * n + j] = (l > 0.0) ? Gc[((long)b * ldn + j) * ldn + a] / l : 0.0;
+}
+
+template <int NT>
+static void osj_launch_sweep(EigPlan* p, hipStream_t st) {
+  // one sweep = every column pair exactly once: one INTRA launch (pairs inside each group of 2*CB
+  // columns... i.e. inside each block pair (2b, 2b+1)) followed by the block-pair rounds; the pair
+  // (2b, 2b+1) itself meets in the round-robin too, where only its CROSS pairs are left to do.
+  const int nb = p->ldn / OSJ_CB;
+  // INTRA: pairs within each single block.  Run as MODE 2 on "super blocks" of 2*CB columns would also
+  // rotate the cross pairs of (2b, 2b+1); instead launch MODE 2 with half-size blocks: CB/2 columns per
+  // block -> 2*(CB/2) = CB columns per workgroup = exactly one block.
+  hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
+                     2 * nb, 0, (double*)nullptr);
+  for (int round = 0; round < nb - 1; ++round)
+    hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, NT, 1>), dim3(nb / 2, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
+                       nb, round, (double*)nullptr);
+}
+
+static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
+  for (int sw = 0; sw < p->sweeps; ++sw) {
+    switch (p->ldn) {
+      case 64: osj_launch_sweep<64>(p, st); break;
+      case 128: osj_launch_sweep<128>(p, st); break;
+      case 192: osj_launch_sweep<192>(p, st); break;
+      case 256: osj_launch_sweep<256>(p, st); break;
+      case 320: osj_launch_sweep<320>(p, st); break;
+      case 384: osj_launch_sweep<384>(p, st); break;
+      case 448: osj_launch_sweep<448>(p, st); break;
+      case 512: osj_launch_sweep<512>(p, st); break;
+      case 640: osj_launch_sweep<640>(p, st); break;
+      case 768: osj_launch_sweep<768>(p, st); break;
+      case 896: osj_launch_sweep<896>(p, st); break;
+      case 1024: osj_launch_sweep<1024>(p, st); break;
+      default: set_error("osj: unsupported padded order %d", p->ldn); return MUSED_ERR_UNSUPPORTED;
+    }
+  }
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
+static int osj_padded_order(int n) {
+  if (n <= 512) return ((n + 63) / 64) * 64;
+  return ((n + 127) / 128) * 128;
+}
+
 static int enqueue_sweeps(EigPlan* p, hipStream_t st) {
   const int n = p->n, h = n / 2;
   dim3 grid(cdiv(h, 16), cdiv(h, 16), p->batch);
@@ -154,17 +503,27 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
   EigPlan* p = new EigPlan();
   memset(p, 0, sizeof(*p));
   p->n = n; p->batch = batch; p->sweeps = sweeps;
+  const char* em = getenv("MUSED_EIG");
+  p->method = (em && em[0] == '0') ? 0 : 1;
+  if (n > 1024) p->method = 0;
   const size_t bytes = sizeof(double) * (size_t)batch * n * n;
-  for (int i = 0; i < 2; ++i) {
-    MUSED_CHECK_HIP(hipMalloc(&p->G[i], bytes));
-    MUSED_CHECK_HIP(hipMalloc(&p->V[i], bytes));
+  if (p->method == 1) {
+    p->ldn = osj_padded_order(n);
+    MUSED_CHECK_HIP(hipMalloc(&p->G[0], bytes));
+    MUSED_CHECK_HIP(hipMalloc(&p->Gc, sizeof(double) * (size_t)batch * p->ldn * p->ldn));
+    MUSED_CHECK_HIP(hipMalloc(&p->lam, sizeof(double) * (size_t)batch * p->ldn));
+  } else {
+    for (int i = 0; i < 2; ++i) {
+      MUSED_CHECK_HIP(hipMalloc(&p->G[i], bytes));
+      MUSED_CHECK_HIP(hipMalloc(&p->V[i], bytes));
+    }
   }
   p->have_graph = false;
   const char* ng = getenv("MUSED_NO_GRAPH");
   if (own_graph && !(ng && ng[0] == '1')) {
     MUSED_CHECK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
     MUSED_CHECK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_sweeps(p, p->cap_stream);
+    const int rc = (p->method == 1) ? osj_enqueue_sweeps(p, p->cap_stream) : enqueue_sweeps(p, p->cap_stream);
     hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph);
     if (rc < 0 || e != hipSuccess) {
       set_error("eig_plan_create: graph capture failed (%s)", hipGetErrorString(e));
@@ -185,15 +544,32 @@ void eig_plan_destroy(EigPlan* p) {
     (void)hipStreamDestroy(p->cap_stream);
   }
   for (int i = 0; i < 2; ++i) {
-    (void)hipFree(p->G[i]);
-    (void)hipFree(p->V[i]);
+    if (p->G[i]) (void)hipFree(p->G[i]);
+    if (p->V[i]) (void)hipFree(p->V[i]);
   }
+  if (p->Gc) (void)hipFree(p->Gc);
+  if (p->lam) (void)hipFree(p->lam);
   delete p;
 }
 
 double* eig_plan_input(EigPlan* p) { return p->G[0]; }
 
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, bool allow_graph) {
+  if (p->method == 1) {
+    const long per = (long)p->ldn * p->ldn;
+    hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc);
+    if (p->have_graph && allow_graph) {
+      MUSED_CHECK_HIP(hipGraphLaunch(p->exec, st));
+    } else {
+      const int rc = osj_enqueue_sweeps(p, st);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam);
+    hipLaunchKernelGGL(osj_extract_kernel, dim3(cdiv((long)p->n * p->n, 256), p->batch), dim3(256), 0, st, p->Gc, p->lam,
+                       p->n, p->ldn, evals, V);
+    MUSED_LAUNCH_CHECK();
+    return MUSED_OK;
+  }
   const long total = (long)p->batch * p->n * p->n;
   hipLaunchKernelGGL(eig_init_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p->V[0], p->n, total);
   int fin;

@@ -17,18 +17,54 @@ namespace mused {
 constexpr int PANEL_ROWS_PER_WG = 512;
 
 // ---------------------------------------------------------------- LU -------------
-__global__ __launch_bounds__(1024) void lu_pivot_kernel(double* __restrict__ Y, int n, int r, long ld, int j,
+constexpr int LU_ROWS_PER_WG = 16;
+
+// partial pivot candidates of column jc: per workgroup (16 rows) the largest |a| among unpivoted rows
+// (ties: smaller row).  A single workgroup scanning a strided column costs ~15 us at n = 10^4 (one
+// cache line per element through one CU); spread over the update grid it is free.
+__device__ __forceinline__ void lu_partial_colmax(const double* __restrict__ Y, int n, long ld, int jc,
+                                                  const int* __restrict__ pivstep, double* __restrict__ pval,
+                                                  int* __restrict__ pidx) {
+  __shared__ double sv[LU_ROWS_PER_WG];
+  __shared__ int si[LU_ROWS_PER_WG];
+  const int lr = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int row = blockIdx.x * LU_ROWS_PER_WG + lr;
+  if (tx == 0) {
+    double a = -1.0;
+    if (row < n && pivstep[row] == 0) a = fabs(Y[(long)row * ld + jc]);
+    sv[lr] = a;
+    si[lr] = row;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = sv[0];
+    int ix = si[0];
+    for (int w = 1; w < LU_ROWS_PER_WG; ++w)
+      if (sv[w] > b) { b = sv[w]; ix = si[w]; }  // rows ascend with w: first maximum = smallest row
+    pval[blockIdx.x] = b;
+    pidx[blockIdx.x] = ix;
+  }
+}
+
+__global__ __launch_bounds__(256) void lu_colmax_kernel(const double* __restrict__ Y, int n, long ld, int jc,
+                                                       const int* __restrict__ pivstep, double* __restrict__ pval,
+                                                       int* __restrict__ pidx) {
+  lu_partial_colmax(Y, n, ld, jc, pivstep, pval, pidx);
+}
+
+// reduce the per-workgroup candidates, mark the pivot row, copy it to prow
+__global__ __launch_bounds__(1024) void lu_pivot_kernel(const double* __restrict__ Y, int npart, int r, long ld, int j,
+                                                       const double* __restrict__ pval, const int* __restrict__ pidx,
                                                        int* __restrict__ pivstep, double* __restrict__ prow) {
   __shared__ double s_val[16];
   __shared__ int s_idx[16];
   __shared__ int s_win;
-  double best = -1.0;
+  double best = -2.0;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    if (pivstep[i] == 0) {
-      const double a = fabs(Y[(long)i * ld + j]);
-      if (a > best || (a == best && i < bi)) { best = a; bi = i; }
-    }
+  for (int i = threadIdx.x; i < npart; i += 1024) {
+    const double a = pval[i];
+    const int ix = pidx[i];
+    if (a > best || (a == best && ix < bi)) { best = a; bi = ix; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -51,19 +87,26 @@ __global__ __launch_bounds__(1024) void lu_pivot_kernel(double* __restrict__ Y, 
   for (int c = j + threadIdx.x; c < r; c += 1024) prow[c] = Y[(long)win * ld + c];
 }
 
-// rows not yet pivoted: l = a_ij * (1 / pivot); a_ij <- l; a_ic -= l * prow[c]  (c > j)
-__global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ Y, int n, int r, long ld, int j,
+// rows not yet pivoted: l = a_ij * (1 / pivot); a_ij <- l; a_ic -= l * prow[c]  (c > j); then the
+// workgroup's pivot candidate for column j + 1
+__global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ Y, int n, int r, long ld, int j, int k,
                                                        const int* __restrict__ pivstep,
-                                                       const double* __restrict__ prow) {
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+                                                       const double* __restrict__ prow, double* __restrict__ pval,
+                                                       int* __restrict__ pidx) {
+  const int row = blockIdx.x * LU_ROWS_PER_WG + (threadIdx.x >> 4);
   const int tx = threadIdx.x & 15;
-  if (row >= n || pivstep[row] != 0) return;
-  double* y = Y + (long)row * ld;
-  const double piv = prow[j];
-  const double a = y[j];
-  const double l = (piv != 0.0) ? a * (1.0 / piv) : a;
-  for (int c = j + 1 + tx; c < r; c += 16) y[c] -= l * prow[c];
-  if (tx == 0) y[j] = l;
+  if (row < n && pivstep[row] == 0) {
+    double* y = Y + (long)row * ld;
+    const double piv = prow[j];
+    const double a = y[j];
+    const double l = (piv != 0.0) ? a * (1.0 / piv) : a;
+    for (int c = j + 1 + tx; c < r; c += 16) y[c] -= l * prow[c];
+    if (tx == 0) y[j] = l;
+  }
+  if (j + 1 < k) {
+    __syncthreads();  // column j + 1 of this workgroup's rows is final (written by lanes of the same waves)
+    lu_partial_colmax(Y, n, ld, j + 1, pivstep, pval, pidx);
+  }
 }
 
 // pivot rows: unit diagonal at their step, zeros to the right; keep only k = min(n, r) columns
@@ -78,12 +121,17 @@ __global__ void lu_finalize_kernel(double* __restrict__ Y, int n, int k, long ld
 }
 
 int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, hipStream_t st) {
+  // workspace layout: pivstep[n] ints, then npart ints of candidate rows; prow[r] doubles, then npart doubles
   const int k = n < r ? n : r;
+  const int npart = cdiv(n, LU_ROWS_PER_WG);
+  int* pidx = pivstep + n;
+  double* pval = prow + r;
   int zrc = zero_ints(pivstep, n, st);
   if (zrc) return zrc;
+  hipLaunchKernelGGL(lu_colmax_kernel, dim3(npart), dim3(256), 0, st, Y, n, ld, 0, pivstep, pval, pidx);
   for (int j = 0; j < k; ++j) {
-    hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, Y, n, r, ld, j, pivstep, prow);
-    hipLaunchKernelGGL(lu_update_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, Y, n, r, ld, j, pivstep, prow);
+    hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, Y, npart, r, ld, j, pval, pidx, pivstep, prow);
+    hipLaunchKernelGGL(lu_update_kernel, dim3(npart), dim3(256), 0, st, Y, n, r, ld, j, k, pivstep, prow, pval, pidx);
   }
   hipLaunchKernelGGL(lu_finalize_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, Y, n, k, ld, pivstep);
   MUSED_LAUNCH_CHECK();
@@ -208,7 +256,8 @@ using namespace mused;
 extern "C" {
 
 // In place: Y (n x r, ld) <- P*L of its LU factorisation with partial pivoting, first
-// min(n, r) columns (scipy.linalg.lu(Y, permute_l=True)[0]).  ws_int: n ints, ws_f64: r doubles.
+// min(n, r) columns (scipy.linalg.lu(Y, permute_l=True)[0]).
+// ws_int: n + ceil(n/16) ints, ws_f64: r + ceil(n/16) doubles.
 int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws_f64, void* stream) {
   MUSED_REQUIRE(Y && ws_int && ws_f64 && n > 0 && r > 0 && ld >= r, "mused_lu_permute_l: bad arguments");
   return lu_permute_l(Y, n, r, ld, ws_int, ws_f64, (hipStream_t)stream);

@@ -205,10 +205,10 @@ int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out
   ALLOC(h->deg, 4 * (size_t)n_max); ALLOC(h->degT, 4 * (size_t)n_max);
   ALLOC(h->rowptr, 4 * (size_t)(n_max + 1)); ALLOC(h->rowptrT, 4 * (size_t)(n_max + 1));
   ALLOC(h->colidx, 4 * (size_t)nnz_cap); ALLOC(h->colidxT, 4 * (size_t)nnz_cap);
-  ALLOC(h->stats, 4 * 8); ALLOC(h->flags, 4 * 4); ALLOC(h->pivstep, 4 * (size_t)n_max);
+  ALLOC(h->stats, 4 * 8); ALLOC(h->flags, 4 * 4); ALLOC(h->pivstep, 4 * ((size_t)n_max + cdiv(n_max, 16)));
   ALLOC(h->Q0, panel); ALLOC(h->Qa, panel); ALLOC(h->Qb, panel); ALLOC(h->Qf, panel); ALLOC(h->Bt, panel);
   ALLOC(h->Vsel, panel); ALLOC(h->embed, panel);
-  ALLOC(h->prow, 8 * (size_t)r_max); ALLOC(h->tau, 8 * (size_t)r_max);
+  ALLOC(h->prow, 8 * ((size_t)r_max + cdiv(n_max, 16))); ALLOC(h->tau, 8 * (size_t)r_max);
   ALLOC(h->wpart, 8 * (size_t)r_max * cdiv(n_max, 512));
   ALLOC(h->gpart, 8 * (size_t)nsplit * r_max * r_max);
   ALLOC(h->evals, 8 * (size_t)h->eig_n); ALLOC(h->U, 8 * (size_t)h->eig_n * h->eig_n);

@@ -405,7 +405,7 @@ int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) 
   h->cap = 2 * ell;
   h->n2 = 2 * ell;
   h->n4 = 4 * ell;
-  h->sweeps = sweeps > 0 ? sweeps : 12;
+  h->sweeps = sweeps > 0 ? sweeps : (2 * ell <= 256 ? 11 : 13);
   h->restart_mark = -1;
   const size_t S = h->S, n2 = h->n2, n4 = h->n4, cap = h->cap, dd = d, l = ell;
 #define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))
@@ -429,7 +429,7 @@ int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) 
   int rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
   if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig))) return rc;
-  if ((rc = eig_plan_create(h->n4, 1, h->sweeps + 1, true, &h->eigq))) return rc;
+  if ((rc = eig_plan_create(h->n4, 1, h->sweeps + 2, true, &h->eigq))) return rc;
   *out = h;
   return MUSED_OK;
 }

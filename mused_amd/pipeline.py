@@ -47,6 +47,9 @@ class StreamPipeline:
         self.latencies = []
         self._pool = ThreadPoolExecutor(max_workers=1) if async_labels else None
         self._pending = deque()
+        # the feature-row sketch is independent of the adjacency / eigenstep of the same window: it
+        # runs on its own HIP stream and the two meet again before the results are handed to the host
+        self._side = torch.cuda.Stream() if feature_sketch else None
 
     # ---- device side of one window --------------------------------------------------------------
     def window_device(self, mods):
@@ -62,8 +65,12 @@ class StreamPipeline:
             if self.fswfd is None:
                 R = float((X.double() ** 2).sum(dim=1).max().item())
                 self.fswfd = SeqBasedSWFD(N=self.W, R=R, d=X.shape[1], sketch_dim=self.ell)
-            self.fswfd.fit(X)
-            self.feature_B, self.feature_sigma, _ = self.fswfd.get_device()
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                X.record_stream(self._side)
+                self.fswfd.fit(X)
+                self.feature_B, self.feature_sigma, _ = self.fswfd.get_device()
         if self.approach == "SWFDMC":
             if self.swfd is None:  # main.py:60-62
                 R = self.eng.max_row_sq_norm(fused)
@@ -96,6 +103,8 @@ class StreamPipeline:
         t_start = time.perf_counter()
         n_clusters = len(np.unique(true_labels_window))  # main.py:41
         reduced, sigma = self.window_device(mods)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
         red_pin = torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True)
         sig_pin = torch.empty(sigma.shape, dtype=sigma.dtype, pin_memory=True)
         red_pin.copy_(reduced, non_blocking=True)
