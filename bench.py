@@ -39,13 +39,16 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blob", choices=["blob", "gauss", "fd"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="window pipelines sharing the GPU, each on its own HIP streams and owning a contiguous "
+                         "block of the rank's windows (1 = strictly one window at a time)")
     return ap.parse_args()
 
 
@@ -170,33 +173,67 @@ def main():
     from mused_amd.pipeline import StreamPipeline
 
     K, Wu = args.steps, args.warmup
-    per_rank = K + Wu
-    first = rank * per_rank  # contiguous block of the global stream; its warm-up windows are the SWFD halo
-    host = [synth.stream_window(args.kind, first + t, W, d, args.seed) for t in range(per_rank)]
-    rows = [torch.from_numpy(x).cuda() for x, _ in host]  # inputs resident in HBM before timing
-    labels = [l for _, l in host]
+    S = max(1, min(args.streams, K))
+    # The rank's K timed windows are split into S contiguous blocks, one per pipeline; every block is
+    # preceded in the stream by its Wu warm-up windows, which double as the SWFD halo (see
+    # mused_amd/distributed.py).  Global window indices of this rank start at `first`.
+    blocks = [K // S + (1 if p < K % S else 0) for p in range(S)]
+    per_rank = K + S * Wu
+    first = rank * per_rank
+    bases, b = [], first
+    for p in range(S):
+        bases.append(b)
+        b += Wu + blocks[p]
+    host = [[synth.stream_window(args.kind, bases[p] + t, W, d, args.seed) for t in range(Wu + blocks[p])]
+            for p in range(S)]
+    rows = [[torch.from_numpy(x).cuda() for x, _ in hp] for hp in host]  # inputs resident in HBM before timing
+    labels = [[l for _, l in hp] for hp in host]
 
-    pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=not args.no_swfd, async_labels=True)
+    R = None
     if not args.no_swfd:
         # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
-        from mused_amd.swfd import SeqBasedSWFD
-
-        R0 = float((rows[0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
+        R0 = float((rows[0][0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
         R = mdist.broadcast_scalar(R0, 0, device="cuda") if world > 1 else R0
-        pipe.fswfd = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell)
+    pipes = []
+    for p in range(S):
+        pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=not args.no_swfd, async_labels=True,
+                              stream=torch.cuda.Stream() if S > 1 else None)
+        if not args.no_swfd:
+            from mused_amd.swfd import SeqBasedSWFD
 
-    for t in range(Wu):
-        pipe.process_window([rows[t]], labels[t], trigger=(first + t + 1) * W - 1)
-    pipe.flush()
-    n_warm_lat = len(pipe.latencies)
+            pipe.fswfd = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell)
+        pipes.append(pipe)
+    torch.cuda.synchronize()
+
+    def trig(p, t):
+        return (bases[p] + t + 1) * W - 1
+
+    import threading
+
+    def drive(p, lo, hi):
+        # one host thread per pipeline: a launch that blocks on a full HIP queue must not stall the others
+        for t in range(lo, hi):
+            pipes[p].process_window([rows[p][t]], labels[p][t], trigger=trig(p, t))
+        pipes[p].flush()
+
+    def run_all(ranges):
+        if S == 1:
+            drive(0, *ranges[0])
+            return
+        ths = [threading.Thread(target=drive, args=(p, *ranges[p])) for p in range(S)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+
+    run_all([(0, Wu)] * S)
+    n_warm_lat = [len(pipe.latencies) for pipe in pipes]
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(Wu, per_rank):
-        pipe.process_window([rows[t]], labels[t], trigger=(first + t + 1) * W - 1)
-    pipe.flush()
+    run_all([(Wu, Wu + blocks[p]) for p in range(S)])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -205,16 +242,17 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    pipe = pipes[0]
 
     # label chain across ranks (outside the timed region: W ints per window)
-    raw_local = np.array([tr["raw"] for tr in pipe.trace[Wu:]], dtype=np.int64)
+    raw_local = np.array([tr["raw"] for pp in pipes for tr in pp.trace[Wu:]], dtype=np.int64)
     counts = [K] * world
     raw_all = mdist.gather_raw_labels(raw_local, counts, device="cuda")
     all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
 
     if rank == 0:
-        lat = np.array(pipe.latencies[n_warm_lat:])
-        stages = stage_profile(cfg, rows[-1], pipe)
+        lat = np.array([x for pp, nw in zip(pipes, n_warm_lat) for x in pp.latencies[nw:]])
+        stages = stage_profile(cfg, rows[0][-1], pipe)
         # ---- roofline of the dominant kernel (measured live with HIP events above) ----
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
         gemm_s = stages["scores_gemm_ms"] * 1e-3
@@ -247,7 +285,8 @@ def main():
                 "stream": args.kind,
                 "W": W, "d": d, "l": ell, "k": k, "modalities": 1,
                 "swfd_levels": stages.get("swfd_levels"),
-                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s)",
+                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {S} concurrent pipeline(s) per GPU",
+                "pipelines_per_gpu": S,
                 "labels_sha16": __import__("hashlib").sha256(all_labels.astype(np.int64).tobytes()).hexdigest()[:16],
             },
             "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
@@ -259,7 +298,8 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    pipe.close()
+    for pp in pipes:
+        pp.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -301,9 +301,11 @@ __host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
   return CROSS ? (c2 / 2 + (k + step) % (c2 / 2)) : osj_pair_q(c2, step, k);
 }
 
-template <int CB, int NT, int MODE>
+template <int CB, int NT, int MODE, int DBG = 0>
 __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
                                                       double* __restrict__ conv) {
+  // DBG != 0: timing-only ablations (results are wrong): 1 no wave reduce, 2 no rotation maths,
+  // 3 no barrier, 4 no rotation apply.
   // MODE 0: block pair, all pairs; MODE 1: block pair, cross pairs only; MODE 2: ONE block of 2*CB
   // consecutive columns (blockIdx.x), all pairs inside it.
   constexpr bool CROSS = (MODE == 1);
@@ -357,9 +359,15 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
 #pragma unroll
     for (int k = 0; k < CB; ++k) dv[k] = x[osj_sched_p<CROSS>(C2, step, k)] * x[osj_sched_q<CROSS>(C2, step, k)];
     int idx;
-    const double t = wave_treduce<CB>(dv, lane, idx);
+    double t;
+    if constexpr (DBG == 1) {
+      t = dv[0] + dv[CB - 1];
+      idx = lane & (CB - 1);
+    } else {
+      t = wave_treduce<CB>(dv, lane, idx);
+    }
     if ((lane & ((64 / CB) - 1)) == 0) part[buf][wave][idx] = t;
-    __syncthreads();
+    if constexpr (DBG != 3) __syncthreads();
     double c = 1.0, s = 0.0;
     if (lane < CB) {  // every wave computes all CB rotations redundantly: no second barrier
       double pq = 0.0;
@@ -377,7 +385,11 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
         q = a < b ? b : a;
       }
       double npp, nqq;
-      osj_rotation(nrm[wave][p], nrm[wave][q], pq, c, s, npp, nqq);
+      if constexpr (DBG == 2) {
+        c = 0.8; s = 0.6; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
+      } else {
+        osj_rotation(nrm[wave][p], nrm[wave][q], pq, c, s, npp, nqq);
+      }
       // de Rijk: keep the larger column in the lower position (a reflection instead of a rotation
       // when the norms come out in the wrong order) -- speeds convergence on graded spectra
       const bool sw = npp < nqq;
@@ -391,8 +403,12 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
       const double4 m4 = csw[wave][k];
       const int p = osj_sched_p<CROSS>(C2, step, k), q = osj_sched_q<CROSS>(C2, step, k);
       const double xp = x[p], xq = x[q];
-      x[p] = m4.x * xp + m4.y * xq;
-      x[q] = m4.z * xp + m4.w * xq;
+      if constexpr (DBG == 4) {
+        x[p] = xp + m4.x;
+      } else {
+        x[p] = m4.x * xp + m4.y * xq;
+        x[q] = m4.z * xp + m4.w * xq;
+      }
     }
   }
 #pragma unroll
@@ -597,6 +613,40 @@ int eig_plan_run(EigPlan* p, const double* G, double* evals, double* V, hipStrea
 using namespace mused;
 
 extern "C" {
+
+// Diagnostic: average kernel time (us, HIP events) of `reps` cross-round launches of the one-sided Jacobi
+// kernel on `batch` matrices of order 256, for timing ablation `variant` (0 = the real kernel).
+int mused_debug_osj_time(const double* init, int batch, int variant, int reps, double* out_us, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int ldn = 256, nb = ldn / OSJ_CB;
+  double* G = nullptr;
+  MUSED_CHECK_HIP(hipMalloc(&G, sizeof(double) * (size_t)batch * ldn * ldn));
+  MUSED_CHECK_HIP(hipMemcpy(G, init, sizeof(double) * (size_t)batch * ldn * ldn, hipMemcpyDeviceToDevice));
+  hipEvent_t e0, e1;
+  MUSED_CHECK_HIP(hipEventCreate(&e0));
+  MUSED_CHECK_HIP(hipEventCreate(&e1));
+  auto launch = [&](int round) {
+    dim3 grid(nb / 2, batch), blk(256);
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 1>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
+      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
+      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
+      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
+      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr);
+    }
+  };
+  MUSED_CHECK_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) launch(i % (nb - 1));
+  MUSED_CHECK_HIP(hipEventRecord(e1, st));
+  MUSED_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MUSED_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *out_us = 1e3 * ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(G);
+  return MUSED_OK;
+}
 
 // Unit-testable primitive: eigen-decomposition of `batch` symmetric n x n fp64 matrices
 // (n even).  evals: batch x n (unsorted), V: batch x n x n with V[:, j] the eigenvector of

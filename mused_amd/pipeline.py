@@ -30,7 +30,7 @@ from .swfd import SeqBasedSWFD
 
 class StreamPipeline:
     def __init__(self, window_size, reduced_dim, k_basis, seed, approach="sSVDMC", modality_types=None,
-                 step_window_ratio=1, engine=None, async_labels=True, feature_sketch=False):
+                 step_window_ratio=1, engine=None, async_labels=True, feature_sketch=False, stream=None):
         if approach not in ("sSVDMC", "sSVDMC_hung", "SWFDMC"):
             raise ValueError(f"approach {approach!r} is not on the device hot path")
         self.W, self.ell, self.k, self.seed = int(window_size), int(reduced_dim), int(k_basis), int(seed)
@@ -49,7 +49,16 @@ class StreamPipeline:
         self._pending = deque()
         # the feature-row sketch is independent of the adjacency / eigenstep of the same window: it
         # runs on its own HIP stream and the two meet again before the results are handed to the host
-        self._side = torch.cuda.Stream() if feature_sketch else None
+        # (only when this pipeline has the GPU to itself: HIP maps streams onto a handful of hardware
+        # queues -- 4 by default -- and streams sharing a queue run in order, so concurrent pipelines
+        # use ONE stream each and overlap with each other instead)
+        self._side = torch.cuda.Stream() if (feature_sketch and stream is None) else None
+        # all device work of this pipeline is enqueued on `stream` (default: the current stream), so
+        # several pipelines -- each owning a contiguous block of windows -- can share one GPU
+        self._stream = stream
+        # pinned staging buffers are recycled: allocating pinned memory synchronises the device, which
+        # would serialise concurrent pipelines
+        self._pins = []
 
     # ---- device side of one window --------------------------------------------------------------
     def window_device(self, mods):
@@ -65,10 +74,14 @@ class StreamPipeline:
             if self.fswfd is None:
                 R = float((X.double() ** 2).sum(dim=1).max().item())
                 self.fswfd = SeqBasedSWFD(N=self.W, R=R, d=X.shape[1], sketch_dim=self.ell)
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                X.record_stream(self._side)
+            if self._side is not None:
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    X.record_stream(self._side)
+                    self.fswfd.fit(X)
+                    self.feature_B, self.feature_sigma, _ = self.fswfd.get_device()
+            else:
                 self.fswfd.fit(X)
                 self.feature_B, self.feature_sigma, _ = self.fswfd.get_device()
         if self.approach == "SWFDMC":
@@ -97,20 +110,32 @@ class StreamPipeline:
     def _finish(self, job):
         ev, red_pin, sig_pin, n_clusters, trigger, t_start = job
         ev.synchronize()
-        self._labels(red_pin.numpy(), n_clusters, trigger, sig_pin.numpy().copy(), t_start)
+        self._labels(red_pin.numpy().copy(), n_clusters, trigger, sig_pin.numpy().copy(), t_start)
+        self._pins.append((red_pin, sig_pin))
+
+    def _get_pins(self, reduced, sigma):
+        while True:
+            for i, (rp, sp) in enumerate(self._pins):
+                if rp.shape == reduced.shape and sp.shape == sigma.shape:
+                    return self._pins.pop(i)
+            if len(self._pending) >= 3:  # back-pressure: reuse a buffer instead of growing the pool
+                self._pending.popleft().result()
+                continue
+            return (torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True),
+                    torch.empty(sigma.shape, dtype=sigma.dtype, pin_memory=True))
 
     def process_window(self, mods, true_labels_window, trigger=None):
         t_start = time.perf_counter()
         n_clusters = len(np.unique(true_labels_window))  # main.py:41
-        reduced, sigma = self.window_device(mods)
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
-        red_pin = torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True)
-        sig_pin = torch.empty(sigma.shape, dtype=sigma.dtype, pin_memory=True)
-        red_pin.copy_(reduced, non_blocking=True)
-        sig_pin.copy_(sigma, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream()):
+            reduced, sigma = self.window_device(mods)
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
+            red_pin, sig_pin = self._get_pins(reduced, sigma)
+            red_pin.copy_(reduced, non_blocking=True)
+            sig_pin.copy_(sigma, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start)
         if self._pool is None:
             self._finish(job)
