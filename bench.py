@@ -46,9 +46,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="window pipelines sharing the GPU, each on its own HIP streams and owning a contiguous "
-                         "block of the rank's windows (1 = strictly one window at a time)")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
+                         "launches (1 = strictly one window at a time)")
     return ap.parse_args()
 
 
@@ -66,7 +66,7 @@ def hip_event_ms(fn, stream, reps=1):
     return e0.elapsed_time(e1) / reps
 
 
-def stage_profile(cfg, X, pipe):
+def stage_profile(cfg, X, pipe, sketch, rows_all):
     """Per-stage device times (ms, HIP events on the launch stream) for one resident window, plus
     the live roofline measurement of the dominant kernels."""
     import ctypes as C
@@ -95,13 +95,13 @@ def stage_profile(cfg, X, pipe):
     f_rsvd = lambda: eng.svd_reduce(adj, ell, pipe.seed, nnz_cap=W * k)
     f_rsvd()
     out["rsvd_ms"] = hip_event_ms(f_rsvd, st, 2)
-    if pipe.fswfd is not None:
-        sk = pipe.fswfd
-        f_app = lambda: sk.fit(X)
-        out["swfd_append_ms"] = hip_event_ms(f_app, st, 1)
-        f_get = lambda: sk.get_device()
-        out["swfd_query_ms"] = hip_event_ms(f_get, st, 1)
-        out["swfd_levels"] = sk.L
+    if sketch is not None:
+        f_app = lambda: sketch.fit_lanes(rows_all[:, -1])
+        out["swfd_append_ms_all_lanes"] = hip_event_ms(f_app, st, 1)
+        f_get = lambda: sketch.get_device()
+        out["swfd_query_ms_all_lanes"] = hip_event_ms(f_get, st, 1)
+        out["swfd_levels"] = sketch.L
+        out["swfd_lanes"] = sketch.lanes
     return out
 
 
@@ -173,67 +173,84 @@ def main():
     from mused_amd.pipeline import StreamPipeline
 
     K, Wu = args.steps, args.warmup
-    S = max(1, min(args.streams, K))
-    # The rank's K timed windows are split into S contiguous blocks, one per pipeline; every block is
-    # preceded in the stream by its Wu warm-up windows, which double as the SWFD halo (see
-    # mused_amd/distributed.py).  Global window indices of this rank start at `first`.
-    blocks = [K // S + (1 if p < K % S else 0) for p in range(S)]
-    per_rank = K + S * Wu
-    first = rank * per_rank
-    bases, b = [], first
-    for p in range(S):
-        bases.append(b)
-        b += Wu + blocks[p]
-    host = [[synth.stream_window(args.kind, bases[p] + t, W, d, args.seed) for t in range(Wu + blocks[p])]
-            for p in range(S)]
-    rows = [[torch.from_numpy(x).cuda() for x, _ in hp] for hp in host]  # inputs resident in HBM before timing
+    # Window-level concurrency on one GPU: the rank's K timed windows are split into B contiguous
+    # blocks ("lanes").  The B sketch sets advance in LOCKSTEP inside the same kernel launches
+    # (mused_swfd_*_lanes) on one HIP stream / host thread; adjacency + eigenstep + labels of the same
+    # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
+    # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
+    B = max(1, min(args.lanes, K))
+    while K % B:
+        B -= 1
+    blk = K // B
+    T = Wu + blk                      # windows per lane
+    per_rank = B * T
+    first = rank * per_rank           # global window index of lane 0, window 0
+    host = [[synth.stream_window(args.kind, first + p * T + t, W, d, args.seed) for t in range(T)] for p in range(B)]
+    rows_all = torch.from_numpy(np.stack([np.stack([x for x, _ in hp]) for hp in host])).cuda()  # (B, T, W, d) resident
     labels = [[l for _, l in hp] for hp in host]
 
-    R = None
+    sketch = None
     if not args.no_swfd:
+        from mused_amd.swfd import SeqBasedSWFD
+
         # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
-        R0 = float((rows[0][0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
+        R0 = float((rows_all[0, 0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
         R = mdist.broadcast_scalar(R0, 0, device="cuda") if world > 1 else R0
-    pipes = []
-    for p in range(S):
-        pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=not args.no_swfd, async_labels=True,
-                              stream=torch.cuda.Stream() if S > 1 else None)
-        if not args.no_swfd:
-            from mused_amd.swfd import SeqBasedSWFD
-
-            pipe.fswfd = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell)
-        pipes.append(pipe)
+        sketch = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=B)
+    # different priorities -> different HIP hardware queues (two default-priority streams can land on the
+    # same queue and then run strictly in order)
+    st_sketch, st_main = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)
+    pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=False, async_labels=True, stream=st_main)
     torch.cuda.synchronize()
-
-    def trig(p, t):
-        return (bases[p] + t + 1) * W - 1
 
     import threading
 
-    def drive(p, lo, hi):
-        # one host thread per pipeline: a launch that blocks on a full HIP queue must not stall the others
-        for t in range(lo, hi):
-            pipes[p].process_window([rows[p][t]], labels[p][t], trigger=trig(p, t))
-        pipes[p].flush()
+    sk_events = {}
+    sk_out = {}
 
-    def run_all(ranges):
-        if S == 1:
-            drive(0, *ranges[0])
+    ref = {"ev": None, "t": 0.0}
+
+    def drive_sketch(lo, hi):
+        if sketch is None:
             return
-        ths = [threading.Thread(target=drive, args=(p, *ranges[p])) for p in range(S)]
+        torch.cuda.set_device(local_rank)  # the current device is per host thread
+        with torch.cuda.stream(st_sketch):
+            ref["ev"] = torch.cuda.Event(enable_timing=True)
+            ref["ev"].record()
+            ref["t"] = time.perf_counter()
+            for t in range(lo, hi):
+                t_enq = time.perf_counter()
+                sketch.fit_lanes(rows_all[:, t])
+                sk_out[t] = sketch.get_device()
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                sk_events[t] = (ev, t_enq)
+            if hi > lo:
+                sk_events[hi - 1][0].synchronize()
+
+    def drive_main(lo, hi):
+        # window order of the label chain: lane-major within the rank is restored after the run
+        torch.cuda.set_device(local_rank)
+        for t in range(lo, hi):
+            for p in range(B):
+                pipe.process_window([rows_all[p, t]], labels[p][t], trigger=(first + p * T + t + 1) * W - 1)
+        pipe.flush()
+
+    def run_range(lo, hi):
+        ths = [threading.Thread(target=drive_sketch, args=(lo, hi)), threading.Thread(target=drive_main, args=(lo, hi))]
         for th in ths:
             th.start()
         for th in ths:
             th.join()
 
-    run_all([(0, Wu)] * S)
-    n_warm_lat = [len(pipe.latencies) for pipe in pipes]
+    run_range(0, Wu)
+    n_warm_lat = len(pipe.latencies)
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_all([(Wu, Wu + blocks[p]) for p in range(S)])
+    run_range(Wu, T)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -242,17 +259,25 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    pipe = pipes[0]
+    S = B
 
     # label chain across ranks (outside the timed region: W ints per window)
-    raw_local = np.array([tr["raw"] for pp in pipes for tr in pp.trace[Wu:]], dtype=np.int64)
+    # traces were appended in (t, lane) order; the stream order is lane-major
+    timed = pipe.trace[Wu * B:]
+    raw_local = np.array([timed[(t * B) + p]["raw"] for p in range(B) for t in range(blk)], dtype=np.int64)
     counts = [K] * world
     raw_all = mdist.gather_raw_labels(raw_local, counts, device="cuda")
     all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
 
     if rank == 0:
-        lat = np.array([x for pp, nw in zip(pipes, n_warm_lat) for x in pp.latencies[nw:]])
-        stages = stage_profile(cfg, rows[0][-1], pipe)
+        lat = np.array(pipe.latencies[n_warm_lat:])
+        if sketch is not None and ref["ev"] is not None:
+            # a window is done when its labels AND its sketch are: take the later one.  Sketch group t
+            # completes at t_ref + elapsed(ref event -> its event); latency counts from its enqueue.
+            sk_done = {t: ref["t"] + ref["ev"].elapsed_time(sk_events[t][0]) * 1e-3 for t in range(Wu, T)}
+            sk_lat = np.array([sk_done[t] - sk_events[t][1] for t in range(Wu, T) for _ in range(B)])
+            lat = np.maximum(lat, sk_lat[: len(lat)]) if len(lat) == len(sk_lat) else lat
+        stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all)
         # ---- roofline of the dominant kernel (measured live with HIP events above) ----
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
         gemm_s = stages["scores_gemm_ms"] * 1e-3
@@ -285,8 +310,8 @@ def main():
                 "stream": args.kind,
                 "W": W, "d": d, "l": ell, "k": k, "modalities": 1,
                 "swfd_levels": stages.get("swfd_levels"),
-                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {S} concurrent pipeline(s) per GPU",
-                "pipelines_per_gpu": S,
+                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {S} lock-step lane(s) per GPU",
+                "lanes_per_gpu": S,
                 "labels_sha16": __import__("hashlib").sha256(all_labels.astype(np.int64).tobytes()).hexdigest()[:16],
             },
             "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
@@ -298,8 +323,9 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    for pp in pipes:
-        pp.close()
+    pipe.close()
+    if sketch is not None:
+        sketch.close()
     if world > 1:
         dist.destroy_process_group()
 

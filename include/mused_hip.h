@@ -112,11 +112,19 @@ int mused_gemm_f64_batched(int a_kc, int b_kc, const double* A, long lda, long s
 
 /* SeqBasedSWFD(N=, R=, d=, sketch_dim=) */
 int mused_swfd_create(long N, double R, int d, int sketch_dim, int sweeps, void** handle);
+/* `lanes` independent sketch sets advanced in lockstep by the same launches (windows of `lanes`
+ * contiguous blocks of the stream): sketches, queries and outputs get a leading lane dimension */
+int mused_swfd_create_lanes(long N, double R, int d, int sketch_dim, int sweeps, int lanes, void** handle);
+int mused_swfd_lanes(void* handle);
+/* n_rows rows for every lane; lane b reads rows + b * lane_stride (elements) */
+int mused_swfd_append_lanes(void* handle, const void* rows, int dtype, long n_rows, long ld, long lane_stride,
+                            void* stream);
 int mused_swfd_destroy(void* handle);
 int mused_swfd_levels(void* handle);
 /* .fit(row) for n_rows rows at once (any batching gives the same sketch) */
 int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, long ld, void* stream);
-/* .get(): out_sketch (sketch_dim x d), out_sigma (sketch_dim, may be NULL), out_info = {level, delta} (may be NULL) */
+/* .get(): out_sketch (lanes x sketch_dim x d), out_sigma (lanes x sketch_dim, may be NULL),
+ * out_info (lanes x 2 = {level, delta}, may be NULL) */
 int mused_swfd_query(void* handle, double* out_sketch, double* out_sigma, double* out_info, void* stream);
 int mused_swfd_counters(void* handle, long* rows_seen, int* pending); /* HOST outputs */
 /* state exchange between ranks (one half = the L sketches of kind 0 MAIN / 1 AUX) */

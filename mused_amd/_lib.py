@@ -51,6 +51,9 @@ _PROTOS = {
     "mused_gemm_f64": (_i, [_i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _d, _vp]),
     "mused_gemm_f64_batched": (_i, [_i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _d, _vp]),
     "mused_swfd_create": (_i, [_l, _d, _i, _i, _i, C.POINTER(_vp)]),
+    "mused_swfd_create_lanes": (_i, [_l, _d, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "mused_swfd_lanes": (_i, [_vp]),
+    "mused_swfd_append_lanes": (_i, [_vp, _vp, _i, _l, _l, _l, _vp]),
     "mused_swfd_destroy": (_i, [_vp]),
     "mused_swfd_levels": (_i, [_vp]),
     "mused_swfd_append": (_i, [_vp, _vp, _i, _l, _l, _vp]),

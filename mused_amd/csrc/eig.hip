@@ -149,7 +149,7 @@ __global__ void eig_extract_kernel(const double* __restrict__ G, const double* _
 // compile-time pairing schedule (register indices are constants), and needs only the CB dot
 // products of each step reduced across the workgroup (in-wave transpose-reduce + one LDS hop).
 // Column norms are carried in LDS and updated from the rotation, so each step reduces CB values.
-constexpr int OSJ_CB = 16;
+constexpr int OSJ_CB = 32;
 
 __host__ __device__ constexpr int osj_pair_p(int m2, int step, int k) {
   // round robin on m2 (even) players; returns the smaller index of pair k at `step`
@@ -202,7 +202,7 @@ constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR2
 
 template <int N>
 __device__ __forceinline__ double wave_treduce(double (&v)[N], int lane, int& idx) {
-  static_assert(N == 8 || N == 16 || N == 32, "wave_treduce: N must be 8, 16 or 32");
+  static_assert(N == 8 || N == 16 || N == 32 || N == 64, "wave_treduce: N must be 8, 16, 32 or 64");
   // stage 1: l ^ 32 (N -> N/2)
 #pragma unroll
   for (int i = 0; i < N / 2; ++i) v[i] = swap32_add(v[i], v[i + N / 2]);
@@ -221,29 +221,46 @@ __device__ __forceinline__ double wave_treduce(double (&v)[N], int lane, int& id
   }
   int id = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
   double t;
-  if constexpr (N >= 16) {  // stage 4: half mirror, decided by bit 2 (N/8 -> N/16)
-    const bool hi = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < N / 16; ++i) {
-      const double keep = hi ? v[i + N / 16] : v[i];
-      const double send = hi ? v[i] : v[i + N / 16];
-      v[i] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
-    }
-    id = id * 2 + ((lane >> 2) & 1);
-    if constexpr (N == 32) {  // stage 5: xor 2, decided by bit 1 (2 -> 1)
-      const bool h2 = (lane & 2) != 0;
-      const double keep = h2 ? v[1] : v[0];
-      const double send = h2 ? v[0] : v[1];
-      t = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send);
-      id = id * 2 + ((lane >> 1) & 1);
-    } else {
-      t = v[0] + dpp_mov_f64<DPP_QUAD_XOR2>(v[0]);
-    }
-  } else {
+  if constexpr (N == 8) {
     t = v[0] + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(v[0]);
     t = t + dpp_mov_f64<DPP_QUAD_XOR2>(t);
+    t = t + dpp_mov_f64<DPP_QUAD_XOR1>(t);
+  } else {
+    {  // stage 4: half mirror, decided by bit 2 (N/8 -> N/16)
+      const bool hi = (lane & 4) != 0;
+#pragma unroll
+      for (int i = 0; i < N / 16; ++i) {
+        const double keep = hi ? v[i + N / 16] : v[i];
+        const double send = hi ? v[i] : v[i + N / 16];
+        v[i] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+      }
+      id = id * 2 + ((lane >> 2) & 1);
+    }
+    if constexpr (N == 16) {
+      t = v[0] + dpp_mov_f64<DPP_QUAD_XOR2>(v[0]);
+      t = t + dpp_mov_f64<DPP_QUAD_XOR1>(t);
+    } else {
+      {  // stage 5: xor 2, decided by bit 1 (N/16 -> N/32)
+        const bool hi = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 32; ++i) {
+          const double keep = hi ? v[i + N / 32] : v[i];
+          const double send = hi ? v[i] : v[i + N / 32];
+          v[i] = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send);
+        }
+        id = id * 2 + ((lane >> 1) & 1);
+      }
+      if constexpr (N == 32) {
+        t = v[0] + dpp_mov_f64<DPP_QUAD_XOR1>(v[0]);
+      } else {  // N == 64, stage 6: xor 1, decided by bit 0
+        const bool hi = (lane & 1) != 0;
+        const double keep = hi ? v[1] : v[0];
+        const double send = hi ? v[0] : v[1];
+        t = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send);
+        id = id * 2 + (lane & 1);
+      }
+    }
   }
-  t = t + dpp_mov_f64<DPP_QUAD_XOR1>(t);
   idx = id;
   return t;
 }
@@ -257,31 +274,40 @@ __device__ __forceinline__ double osj_readlane(double v, int l) {
 
 // Plane rotation that zeroes the inner product pq of two columns with squared norms pp, qq:
 //   zeta = (qq - pp) / (2 pq),  t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),  c = 1/sqrt(1 + t^2),  s = t c.
-// One fp64 divide and one fp64 sqrt; the two reciprocals are fp32 hardware seeds refined by Newton
-// steps in fp64 (full fp64 accuracy matters: an angle error d leaves d * sqrt(pp / qq) of cosine
-// between a large and a small column, which stalls convergence on graded spectra).
+// This sits on the critical path of every Jacobi step (one wave-instruction stream, nothing to overlap),
+// so the two divides and two square roots are v_rcp_f64 / v_rsq_f64 seeds refined by Newton steps to
+// full fp64 accuracy (an angle error d would leave d * sqrt(pp / qq) of cosine between a large and a
+// small column and stall convergence on graded spectra) instead of the ~4x longer IEEE sequences.
+__device__ __forceinline__ double osj_rcp(double y) {
+  double r = __builtin_amdgcn_rcp(y);
+  r = fma(r, fma(-y, r, 1.0), r);
+  r = fma(r, fma(-y, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double osj_rsqrt(double h) {
+  double r = __builtin_amdgcn_rsq(h);
+  r = r * fma(-0.5 * h, r * r, 1.5);
+  r = r * fma(-0.5 * h, r * r, 1.5);
+  return r;
+}
 __device__ __forceinline__ void osj_rotation(double pp, double qq, double pq, double& c, double& s, double& npp,
                                              double& nqq) {
   c = 1.0; s = 0.0; npp = pp; nqq = qq;
   if (pq * pq > 1e-30 * (pp * qq) && pq != 0.0) {
-    const double zeta = (qq - pp) / (2.0 * pq);
+    const double zeta = (qq - pp) * osj_rcp(2.0 * pq);
     const double az = fabs(zeta);
     double t;
-    if (az > 1e100) {
-      t = 0.5 / zeta;
+    if (!(az < 1e100)) {
+      t = 0.0;  // |zeta| astronomically large (or the reciprocal overflowed): the angle is below rounding
     } else {
-      const double y = az + sqrt(1.0 + az * az);  // >= 1
-      double r = (double)(1.0f / (float)y);       // 0 if y overflows fp32: t = 0, rotation skipped this time
-      r = r * (2.0 - y * r);
-      r = r * (2.0 - y * r);
+      const double w = fma(az, az, 1.0);
+      const double y = fma(w, osj_rsqrt(w), az);  // |zeta| + sqrt(1 + zeta^2) >= 1
+      const double r = osj_rcp(y);
       t = zeta < 0.0 ? -r : r;
     }
-    const double h = 1.0 + t * t;  // in [1, 2]
-    double c0 = (double)rsqrtf((float)h);
-    c0 = c0 * (1.5 - 0.5 * h * c0 * c0);
-    c0 = c0 * (1.5 - 0.5 * h * c0 * c0);
-    c = c0;
-    s = t * c0;
+    const double h = fma(t, t, 1.0);  // in [1, 2]
+    c = osj_rsqrt(h);
+    s = t * c;
     npp = pp - t * pq;
     nqq = qq + t * pq;
   }
@@ -304,17 +330,26 @@ __host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
 template <int CB, int NT, int MODE, int DBG = 0>
 __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
                                                       double* __restrict__ conv) {
-  // DBG != 0: timing-only ablations (results are wrong): 1 no wave reduce, 2 no rotation maths,
-  // 3 no barrier, 4 no rotation apply.
-  // MODE 0: block pair, all pairs; MODE 1: block pair, cross pairs only; MODE 2: ONE block of 2*CB
-  // consecutive columns (blockIdx.x), all pairs inside it.
+  // MODE 1: block pair (bp, bq) of the round-robin, cross pairs only; MODE 2: ONE block of 2*CB
+  // consecutive columns (blockIdx.x), all pairs inside it; MODE 0: block pair, all pairs.
+  // DBG != 0: timing-only ablations (results are wrong): 2 no rotation maths, 3 no barrier, 4 no apply.
+  //
+  // FAST (scaled) ROTATIONS: column j is held as d_j * x_j with a per-column scale d_j (LDS, starts at
+  // 1).  A rotation (c, s, t = s/c) of the true columns becomes
+  //     x_p <- x_p - (t d_q / d_p) x_q,   x_q <- x_q + (t d_p / d_q) x_p,   d_p, d_q <- c d_p, c d_q
+  // i.e. TWO fmas per element instead of four multiply-adds; 1/d_j is carried too (1/c = c (1 + t^2)),
+  // so no divide.  Scales are folded back into the columns when the launch stores them (<= 2*CB - 1
+  // rotations per column per launch: d >= 2^-16, no underflow).
   constexpr bool CROSS = (MODE == 1);
   constexpr int C2 = 2 * CB;
-  constexpr int NSTEP = CROSS ? CB : C2 - 1;
+  constexpr int NSTEP = (DBG == 5 || DBG == 6) ? 0 : (DBG == 7 ? 4 : (CROSS ? CB : C2 - 1));
   constexpr int NW = NT / 64;
   __shared__ double part[2][NW][C2];  // double-buffered cross-wave partial sums
-  __shared__ double nrm[NW][C2];      // per-wave private copy of the squared column norms
-  __shared__ double4 csw[NW][CB];     // per-wave 2x2 orthogonal maps of the step's CB pairs
+  __shared__ double nrm[NW][C2];      // per-wave private copies: true squared column norms,
+  __shared__ double dsc[NW][C2];      //   column scales d_j
+  __shared__ double isc[NW][C2];      //   and 1 / d_j
+  __shared__ double2 tau[NW][CB];     // per-wave (tau_p, tau_q) of the step's CB pairs
+  __shared__ int dest[NW][C2];        // store position of each column (descending norm)
 
   double* M = Gc + (long)blockIdx.y * ldn * ldn;
   int bp, bq;
@@ -349,6 +384,8 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
 #pragma unroll
       for (int w = 0; w < NW; ++w) sum += part[1][w][lane];
       nrm[wave][lane] = sum;
+      dsc[wave][lane] = 1.0;
+      isc[wave][lane] = 1.0;
     }
     // part[1] is next written at step 1, after the barrier of step 0: no hazard
   }
@@ -359,20 +396,13 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
 #pragma unroll
     for (int k = 0; k < CB; ++k) dv[k] = x[osj_sched_p<CROSS>(C2, step, k)] * x[osj_sched_q<CROSS>(C2, step, k)];
     int idx;
-    double t;
-    if constexpr (DBG == 1) {
-      t = dv[0] + dv[CB - 1];
-      idx = lane & (CB - 1);
-    } else {
-      t = wave_treduce<CB>(dv, lane, idx);
-    }
+    const double t = wave_treduce<CB>(dv, lane, idx);
     if ((lane & ((64 / CB) - 1)) == 0) part[buf][wave][idx] = t;
     if constexpr (DBG != 3) __syncthreads();
-    double c = 1.0, s = 0.0;
     if (lane < CB) {  // every wave computes all CB rotations redundantly: no second barrier
-      double pq = 0.0;
+      double raw = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) pq += part[buf][w][lane];
+      for (int w = 0; w < NW; ++w) raw += part[buf][w][lane];
       int p, q;
       if (CROSS) {
         p = lane;
@@ -384,37 +414,61 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
         p = a < b ? a : b;
         q = a < b ? b : a;
       }
-      double npp, nqq;
+      const double dp = dsc[wave][p], dq = dsc[wave][q];
+      const double pq = raw * dp * dq;
+      double c = 1.0, s = 0.0, npp, nqq;
       if constexpr (DBG == 2) {
         c = 0.8; s = 0.6; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
       } else {
         osj_rotation(nrm[wave][p], nrm[wave][q], pq, c, s, npp, nqq);
       }
-      // de Rijk: keep the larger column in the lower position (a reflection instead of a rotation
-      // when the norms come out in the wrong order) -- speeds convergence on graded spectra
-      const bool sw = npp < nqq;
-      nrm[wave][p] = sw ? nqq : npp;
-      nrm[wave][q] = sw ? npp : nqq;
-      csw[wave][lane] = sw ? make_double4(s, c, c, -s) : make_double4(c, -s, s, c);
+      double tp = 0.0, tq = 0.0;
+      if (s != 0.0) {
+        const double tt = s * (c * (1.0 + (s * s) / (c * c)));  // t = s / c without a divide: 1/c = c (1 + t^2)
+        const double ip = isc[wave][p], iq = isc[wave][q];
+        tp = tt * dq * ip;
+        tq = tt * dp * iq;
+        const double ic = c * (1.0 + tt * tt);
+        nrm[wave][p] = npp;
+        nrm[wave][q] = nqq;
+        dsc[wave][p] = dp * c;
+        dsc[wave][q] = dq * c;
+        isc[wave][p] = ip * ic;
+        isc[wave][q] = iq * ic;
+      }
+      tau[wave][lane] = make_double2(tp, tq);
     }
-    // same wave wrote csw: program order + the compiler's lgkmcnt wait make it visible (no barrier)
+    // same wave wrote tau: program order + the compiler's lgkmcnt wait make it visible (no barrier)
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
-      const double4 m4 = csw[wave][k];
+      const double2 t2 = tau[wave][k];
       const int p = osj_sched_p<CROSS>(C2, step, k), q = osj_sched_q<CROSS>(C2, step, k);
       const double xp = x[p], xq = x[q];
       if constexpr (DBG == 4) {
-        x[p] = xp + m4.x;
+        x[p] = xp + t2.x;
       } else {
-        x[p] = m4.x * xp + m4.y * xq;
-        x[q] = m4.z * xp + m4.w * xq;
+        x[p] = fma(-t2.x, xq, xp);
+        x[q] = fma(t2.y, xp, xq);
       }
     }
   }
+  // de Rijk at block level: store the columns by descending norm (large columns first speeds up the
+  // convergence on graded spectra); fold the scales back in.
+  if (lane < C2) {
+    const double mine = nrm[wave][lane];
+    int rank = 0;
 #pragma unroll
-  for (int j = 0; j < CB; ++j) {
-    M[(long)(bp * CB + j) * ldn + r] = x[j];
-    M[(long)(bq * CB + j) * ldn + r] = x[CB + j];
+    for (int j = 0; j < C2; ++j) {
+      const double o = nrm[wave][j];
+      rank += (o > mine) || (o == mine && j < lane);
+    }
+    dest[wave][lane] = rank;
+  }
+#pragma unroll
+  for (int j = 0; j < C2; ++j) {
+    const int pos = dest[wave][j];
+    const int col = (pos < CB) ? (bp * CB + pos) : (bq * CB + pos - CB);
+    M[(long)col * ldn + r] = x[j] * dsc[wave][j];
   }
   (void)conv;
   (void)n;
@@ -628,7 +682,8 @@ int mused_debug_osj_time(const double* init, int batch, int variant, int reps, d
   auto launch = [&](int round) {
     dim3 grid(nb / 2, batch), blk(256);
     switch (variant) {
-      case 1: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 1>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
+      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
+      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
       case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
       case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
       case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;

@@ -16,12 +16,15 @@
 // Control flow is data independent (the rotation schedule depends only on the row counter),
 // all data-dependent decisions (dumps, expiry, level choice) stay on the device: no host sync
 // anywhere on the update or query path.
+#include <vector>
+
 #include "internal.h"
 
 namespace mused {
 
 struct Swfd {
   int N, d, ell, L, S, cap, n2, n4;
+  int lanes;  // independent sketch sets advanced in lockstep (S = lanes * 2L sketches in every launch)
   double R;
   long i;    // rows seen so far
   int pend;  // rows appended since the last rotation (they sit raw in every buffer)
@@ -46,13 +49,15 @@ struct Swfd {
   EigPlan* eigq;
 };
 
-static inline int sk_index(const Swfd* h, int level, int kind) { return kind * h->L + level; }
+// sketch index = lane * 2L + kind * L + level  (kind 0 = MAIN, 1 = AUX)
+static inline int sk_index(const Swfd* h, int lane, int level, int kind) { return lane * 2 * h->L + kind * h->L + level; }
 
 // ---- update ------------------------------------------------------------------------
 template <typename T>
-__global__ void swfd_append_kernel(const T* __restrict__ X, long ldx, int m, int d, int n2, int pend,
-                                   const int* __restrict__ meta, double* __restrict__ buf) {
+__global__ void swfd_append_kernel(const T* __restrict__ X, long ldx, long lane_stride, int per_lane, int m, int d,
+                                   int n2, int pend, const int* __restrict__ meta, double* __restrict__ buf) {
   const int r = blockIdx.x, s = blockIdx.y;
+  X += (long)(s / per_lane) * lane_stride;
   const int row = meta[s * 4 + 0] + pend + r;
   if (row >= n2) return;  // cannot happen by construction (nk <= l - 1, pend + m <= l)
   double* dst = buf + ((long)s * n2 + row) * d;
@@ -64,8 +69,8 @@ __global__ void swfd_append_kernel(const T* __restrict__ X, long ldx, int m, int
 __global__ void swfd_restart_kernel(double* __restrict__ buf, double* __restrict__ queue, long long* __restrict__ qt,
                                     int* __restrict__ meta, long long* __restrict__ dropped, int L, long buf_elems,
                                     long queue_elems, int cap) {
-  const int j = blockIdx.y;
-  const int sm = j, sa = L + j;
+  const int lane = blockIdx.y / L, j = blockIdx.y - lane * L;
+  const int sm = lane * 2 * L + j, sa = sm + L;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < buf_elems) {
     buf[sm * buf_elems + gid] = buf[sa * buf_elems + gid];
@@ -213,14 +218,14 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
 static int swfd_restart(Swfd* h, hipStream_t st) {
   const long be = (long)h->n2 * h->d, qe = (long)h->cap * h->d;
   const long m = be > qe ? be : qe;
-  hipLaunchKernelGGL(swfd_restart_kernel, dim3(cdiv(m, 256), h->L), dim3(256), 0, st, h->buf, h->queue, h->qt,
+  hipLaunchKernelGGL(swfd_restart_kernel, dim3(cdiv(m, 256), h->L * h->lanes), dim3(256), 0, st, h->buf, h->queue, h->qt,
                      h->meta, h->dropped, h->L, be, qe, h->cap);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }
 
 template <typename T>
-static int swfd_append_t(Swfd* h, const T* X, long ldx, long m, hipStream_t st) {
+static int swfd_append_t(Swfd* h, const T* X, long ldx, long lane_stride, long m, hipStream_t st) {
   long r = 0;
   int rc;
   while (r < m) {
@@ -233,8 +238,8 @@ static int swfd_append_t(Swfd* h, const T* X, long ldx, long m, hipStream_t st) 
     long until = h->ell - (in_epoch % h->ell);
     if (h->N - in_epoch < until) until = h->N - in_epoch;
     const long take = (m - r) < until ? (m - r) : until;
-    hipLaunchKernelGGL(swfd_append_kernel<T>, dim3((int)take, h->S), dim3(256), 0, st, X + r * ldx, ldx, (int)take,
-                       h->d, h->n2, h->pend, h->meta, h->buf);
+    hipLaunchKernelGGL(swfd_append_kernel<T>, dim3((int)take, h->S), dim3(256), 0, st, X + r * ldx, ldx, lane_stride,
+                       2 * h->L, (int)take, h->d, h->n2, h->pend, h->meta, h->buf);
     MUSED_LAUNCH_CHECK();
     h->pend += (int)take;
     h->i += take;
@@ -249,44 +254,56 @@ static int swfd_append_t(Swfd* h, const T* X, long ldx, long m, hipStream_t st) 
 // ---- query ---------------------------------------------------------------------------
 __global__ void swfd_select_kernel(const int* __restrict__ meta, const long long* __restrict__ qt,
                                    const long long* __restrict__ dropped, int L, int cap, int N, long long now,
-                                   int* __restrict__ qsel) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                                   int* __restrict__ qsel_all) {
+  if (threadIdx.x != 0) return;
+  const int lane = blockIdx.x;
+  const int base = lane * 2 * L;  // MAIN sketches of this lane are base .. base + L - 1
+  int* qsel = qsel_all + (long)lane * (4 + cap);
   int lvl = L - 1;
   for (int j = 0; j < L; ++j) {
-    const long long dr = dropped[j];  // MAIN sketches are indices 0 .. L-1
+    const long long dr = dropped[base + j];
     if (dr == 0 || dr + N <= now) { lvl = j; break; }
   }
-  const int head = meta[lvl * 4 + 1], cnt = meta[lvl * 4 + 2];
+  const int sk = base + lvl;
+  const int head = meta[sk * 4 + 1], cnt = meta[sk * 4 + 2];
   int ns = 0;
   for (int q = 0; q < cnt; ++q) {
     const int slot = (head + q) % cap;
-    if (qt[(long)lvl * cap + slot] + N > now) qsel[3 + ns++] = slot;
+    if (qt[(long)sk * cap + slot] + N > now) qsel[4 + ns++] = slot;
   }
   qsel[0] = lvl;
   qsel[1] = ns;
-  qsel[2] = meta[lvl * 4 + 0];
+  qsel[2] = meta[sk * 4 + 0];
+  qsel[3] = sk;
 }
 
-__global__ void swfd_stack_kernel(const int* __restrict__ qsel, const double* __restrict__ buf,
-                                  const double* __restrict__ queue, int n2, int cap, int d, int pend,
+__global__ void swfd_stack_kernel(const int* __restrict__ qsel_all, const double* __restrict__ buf,
+                                  const double* __restrict__ queue, int n2, int n4, int cap, int d, int pend,
                                   double* __restrict__ stack) {
-  const int rho = blockIdx.x;
-  const int lvl = qsel[0], ns = qsel[1], nk = qsel[2];
+  const int rho = blockIdx.x, lane = blockIdx.y;
+  const int* qsel = qsel_all + (long)lane * (4 + cap);
+  const int ns = qsel[1], nk = qsel[2], sk = qsel[3];
   const double* src = nullptr;
-  if (rho < ns) src = queue + ((long)lvl * cap + qsel[3 + rho]) * d;
-  else if (rho < ns + nk + pend) src = buf + ((long)lvl * n2 + (rho - ns)) * d;
-  double* dst = stack + (long)rho * d;
+  if (rho < ns) src = queue + ((long)sk * cap + qsel[4 + rho]) * d;
+  else if (rho < ns + nk + pend) src = buf + ((long)sk * n2 + (rho - ns)) * d;
+  double* dst = stack + ((long)lane * n4 + rho) * d;
   for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src ? src[c] : 0.0;
 }
 
-__global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* __restrict__ evals,
-                                                                const double* __restrict__ U, int n4, int ell,
-                                                                const int* __restrict__ qsel, double* __restrict__ Wq,
-                                                                double* __restrict__ qinfo) {
+__global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* __restrict__ evals_all,
+                                                                const double* __restrict__ U_all, int n4, int ell,
+                                                                int cap, const int* __restrict__ qsel_all,
+                                                                double* __restrict__ Wq_all,
+                                                                double* __restrict__ qinfo_all) {
   __shared__ double lam[1024];
   __shared__ int order[1024];
   __shared__ double scale[512];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = blockIdx.x;
+  const double* evals = evals_all + (long)lane * n4;
+  const double* U = U_all + (long)lane * n4 * n4;
+  const int* qsel = qsel_all + (long)lane * (4 + cap);
+  double* Wq = Wq_all + (long)lane * ell * n4;
+  double* qinfo = qinfo_all + (long)lane * 2;
   if (t < n4) lam[t] = evals[t];
   __syncthreads();
   if (t < n4) {
@@ -326,7 +343,8 @@ __global__ __launch_bounds__(256) void swfd_finish_rows_kernel(double* __restric
   __shared__ int si[4];
   __shared__ double ss[4];
   __shared__ double s_sign;
-  double* row = B + (long)blockIdx.x * d;
+  const long rowid = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  double* row = B + rowid * d;
   double best = -1.0, sq = 0.0;
   int bi = 0x7fffffff;
   for (int c = threadIdx.x; c < d; c += 256) {
@@ -348,7 +366,7 @@ __global__ __launch_bounds__(256) void swfd_finish_rows_kernel(double* __restric
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
     s_sign = (row[bi] < 0.0) ? -1.0 : 1.0;
-    sig[blockIdx.x] = sqrt(ss[0] + ss[1] + ss[2] + ss[3]);
+    sig[rowid] = sqrt(ss[0] + ss[1] + ss[2] + ss[3]);
   }
   __syncthreads();
   if (s_sign < 0.0)
@@ -356,25 +374,27 @@ __global__ __launch_bounds__(256) void swfd_finish_rows_kernel(double* __restric
 }
 
 static int swfd_query(Swfd* h, double* outB, double* outSigma, double* outInfo, hipStream_t st) {
-  const int n4 = h->n4, d = h->d, ell = h->ell;
+  const int n4 = h->n4, d = h->d, ell = h->ell, B = h->lanes;
   int rc;
-  hipLaunchKernelGGL(swfd_select_kernel, dim3(1), dim3(64), 0, st, h->meta, h->qt, h->dropped, h->L, h->cap, h->N,
+  hipLaunchKernelGGL(swfd_select_kernel, dim3(B), dim3(64), 0, st, h->meta, h->qt, h->dropped, h->L, h->cap, h->N,
                      (long long)h->i, h->qsel);
-  hipLaunchKernelGGL(swfd_stack_kernel, dim3(n4), dim3(256), 0, st, h->qsel, h->buf, h->queue, h->n2, h->cap, d,
+  hipLaunchKernelGGL(swfd_stack_kernel, dim3(n4, B), dim3(256), 0, st, h->qsel, h->buf, h->queue, h->n2, n4, h->cap, d,
                      h->pend, h->stack);
-  if ((rc = gemm_f64(true, true, h->stack, d, 0, h->stack, d, 0, eig_plan_input(h->eigq), n4, 0, n4, n4, d, 1, 1.0,
-                     st)))
+  if ((rc = gemm_f64(true, true, h->stack, d, (long)n4 * d, h->stack, d, (long)n4 * d, eig_plan_input(h->eigq), n4,
+                     (long)n4 * n4, n4, n4, d, B, 1.0, st)))
     return rc;
   if ((rc = eig_plan_run_inplace(h->eigq, h->evals_q, h->Uq, st, true))) return rc;
-  hipLaunchKernelGGL(swfd_decide_query_kernel, dim3(1), dim3(1024), 0, st, h->evals_q, h->Uq, n4, ell, h->qsel, h->Wq,
-                     h->qinfo);
-  if ((rc = gemm_f64(true, false, h->Wq, n4, 0, h->stack, d, 0, h->Bout, d, 0, ell, d, n4, 1, 1.0, st))) return rc;
-  hipLaunchKernelGGL(swfd_finish_rows_kernel, dim3(ell), dim3(256), 0, st, h->Bout, d, h->sig_out);
+  hipLaunchKernelGGL(swfd_decide_query_kernel, dim3(B), dim3(1024), 0, st, h->evals_q, h->Uq, n4, ell, h->cap, h->qsel,
+                     h->Wq, h->qinfo);
+  if ((rc = gemm_f64(true, false, h->Wq, n4, (long)ell * n4, h->stack, d, (long)n4 * d, h->Bout, d, (long)ell * d, ell,
+                     d, n4, B, 1.0, st)))
+    return rc;
+  hipLaunchKernelGGL(swfd_finish_rows_kernel, dim3(ell, B), dim3(256), 0, st, h->Bout, d, h->sig_out);
   MUSED_LAUNCH_CHECK();
-  MUSED_CHECK_HIP(hipMemcpyAsync(outB, h->Bout, sizeof(double) * (size_t)ell * d, hipMemcpyDeviceToDevice, st));
+  MUSED_CHECK_HIP(hipMemcpyAsync(outB, h->Bout, sizeof(double) * (size_t)B * ell * d, hipMemcpyDeviceToDevice, st));
   if (outSigma)
-    MUSED_CHECK_HIP(hipMemcpyAsync(outSigma, h->sig_out, sizeof(double) * (size_t)ell, hipMemcpyDeviceToDevice, st));
-  if (outInfo) MUSED_CHECK_HIP(hipMemcpyAsync(outInfo, h->qinfo, sizeof(double) * 2, hipMemcpyDeviceToDevice, st));
+    MUSED_CHECK_HIP(hipMemcpyAsync(outSigma, h->sig_out, sizeof(double) * (size_t)B * ell, hipMemcpyDeviceToDevice, st));
+  if (outInfo) MUSED_CHECK_HIP(hipMemcpyAsync(outInfo, h->qinfo, sizeof(double) * 2 * B, hipMemcpyDeviceToDevice, st));
   return MUSED_OK;
 }
 
@@ -391,8 +411,17 @@ extern "C" {
 
 // Replaces SeqBasedSWFD.__init__ (call site main.py:62: N=window_size, R=max row norm^2,
 // d=row length, sketch_dim=l).  sweeps: Jacobi sweeps per rotation (0 -> default).
+int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int lanes, void** out);
+
 int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) {
+  return mused_swfd_create_lanes(N, R, d, ell, sweeps, 1, out);
+}
+
+// `lanes` independent sketch sets (e.g. the windows of `lanes` contiguous blocks of the stream) advanced
+// in lockstep by the same launches: every append feeds the same number of rows to every lane.
+int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int lanes, void** out) {
   MUSED_REQUIRE(out && N >= 1 && d >= 1 && ell >= 1 && ell <= 256, "mused_swfd_create: need N, d >= 1 and 1 <= sketch_dim <= 256");
+  MUSED_REQUIRE(lanes >= 1 && lanes <= 64, "mused_swfd_create_lanes: 1 <= lanes <= 64");
   MUSED_REQUIRE(N < (1l << 31), "mused_swfd_create: N too large");
   Swfd* h = new Swfd();
   memset(h, 0, sizeof(*h));
@@ -401,7 +430,8 @@ int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) 
   int lg = 0;
   while ((double)(1ull << lg) < r1 && lg < 62) ++lg;  // ceil(log2(R))
   h->L = lg + 1;
-  h->S = 2 * h->L;
+  h->lanes = lanes;
+  h->S = 2 * h->L * lanes;
   h->cap = 2 * ell;
   h->n2 = 2 * ell;
   h->n4 = 4 * ell;
@@ -418,18 +448,21 @@ int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) 
   ALLOC(h->theta, 8 * S);
   ALLOC(h->T, 8 * S * l * dd); ALLOC(h->Wc, 8 * S * l * n2); ALLOC(h->evals, 8 * S * n2); ALLOC(h->U, 8 * S * n2 * n2);
   ALLOC(h->plan, 4 * S * l * 2); ALLOC(h->keep_src, 4 * S * l); ALLOC(h->now_dev, 8);
-  ALLOC(h->stack, 8 * n4 * dd); ALLOC(h->evals_q, 8 * n4); ALLOC(h->Uq, 8 * n4 * n4); ALLOC(h->Wq, 8 * l * n4);
-  ALLOC(h->Bout, 8 * l * dd); ALLOC(h->sig_out, 8 * l); ALLOC(h->qinfo, 8 * 2); ALLOC(h->qsel, 4 * (3 + cap));
+  const size_t Bn = lanes;
+  ALLOC(h->stack, 8 * Bn * n4 * dd); ALLOC(h->evals_q, 8 * Bn * n4); ALLOC(h->Uq, 8 * Bn * n4 * n4);
+  ALLOC(h->Wq, 8 * Bn * l * n4); ALLOC(h->Bout, 8 * Bn * l * dd); ALLOC(h->sig_out, 8 * Bn * l);
+  ALLOC(h->qinfo, 8 * 2 * Bn); ALLOC(h->qsel, 4 * Bn * (4 + cap));
 #undef ZALLOC
 #undef ALLOC
-  double th[128];
-  for (int kind = 0; kind < 2; ++kind)
-    for (int j = 0; j < h->L; ++j) th[sk_index(h, j, kind)] = ldexp((double)h->N / ell, j);
-  MUSED_CHECK_HIP(hipMemcpy(h->theta, th, 8 * S, hipMemcpyHostToDevice));
+  std::vector<double> th(S);
+  for (int lane = 0; lane < lanes; ++lane)
+    for (int kind = 0; kind < 2; ++kind)
+      for (int j = 0; j < h->L; ++j) th[sk_index(h, lane, j, kind)] = ldexp((double)h->N / ell, j);
+  MUSED_CHECK_HIP(hipMemcpy(h->theta, th.data(), 8 * S, hipMemcpyHostToDevice));
   int rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
   if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig))) return rc;
-  if ((rc = eig_plan_create(h->n4, 1, h->sweeps + 2, true, &h->eigq))) return rc;
+  if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq))) return rc;
   *out = h;
   return MUSED_OK;
 }
@@ -452,16 +485,29 @@ int mused_swfd_levels(void* handle) { return handle ? ((Swfd*)handle)->L : -1; }
 // length d (device pointer, row pitch ld elements, dtype MUSED_F32 / F64 / I64 -- the fused matrix
 // is int64 for >= 2 modalities, matrix_operations.py:138).  Any split of the stream into calls
 // gives the same sketch.
+int mused_swfd_append_lanes(void* handle, const void* rows, int dtype, long n_rows, long ld, long lane_stride,
+                            void* stream);
+
 int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, long ld, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && h->lanes == 1, "mused_swfd_append: this handle has %d lanes, use mused_swfd_append_lanes", h ? h->lanes : 0);
+  return mused_swfd_append_lanes(handle, rows, dtype, n_rows, ld, 0, stream);
+}
+
+// n_rows rows for EVERY lane: lane b reads rows + b * lane_stride (elements), row pitch ld.
+int mused_swfd_append_lanes(void* handle, const void* rows, int dtype, long n_rows, long ld, long lane_stride,
+                            void* stream) {
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && (rows || n_rows == 0) && n_rows >= 0 && ld >= h->d, "mused_swfd_append: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MUSED_F32) return swfd_append_t<float>(h, (const float*)rows, ld, n_rows, st);
-  if (dtype == MUSED_F64) return swfd_append_t<double>(h, (const double*)rows, ld, n_rows, st);
-  if (dtype == MUSED_I64) return swfd_append_t<long long>(h, (const long long*)rows, ld, n_rows, st);
+  if (dtype == MUSED_F32) return swfd_append_t<float>(h, (const float*)rows, ld, lane_stride, n_rows, st);
+  if (dtype == MUSED_F64) return swfd_append_t<double>(h, (const double*)rows, ld, lane_stride, n_rows, st);
+  if (dtype == MUSED_I64) return swfd_append_t<long long>(h, (const long long*)rows, ld, lane_stride, n_rows, st);
   set_error("mused_swfd_append: unsupported dtype %d", dtype);
   return MUSED_ERR_UNSUPPORTED;
 }
+
+int mused_swfd_lanes(void* handle) { return handle ? ((Swfd*)handle)->lanes : -1; }
 
 // Replaces SeqBasedSWFD.get() (main.py:70): out_sketch (l x d fp64), out_sigma (l, row norms of the
 // sketch = its singular values), out_info = {level used, delta of the final shrink}.  Device pointers.
@@ -507,12 +553,14 @@ static int half_copy(Swfd* h, int kind, char* blob, bool to_blob, hipStream_t st
 int mused_swfd_export_half(void* handle, int kind, void* dst, void* stream) {
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && dst && (kind == 0 || kind == 1), "mused_swfd_export_half: bad arguments");
+  MUSED_REQUIRE(h->lanes == 1, "mused_swfd_export_half: single-lane handles only");
   return half_copy(h, kind, (char*)dst, true, (hipStream_t)stream);
 }
 
 int mused_swfd_import_half(void* handle, int kind, const void* src, void* stream) {
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && src && (kind == 0 || kind == 1), "mused_swfd_import_half: bad arguments");
+  MUSED_REQUIRE(h->lanes == 1, "mused_swfd_import_half: single-lane handles only");
   return half_copy(h, kind, (char*)src, false, (hipStream_t)stream);
 }
 
@@ -524,12 +572,13 @@ int mused_swfd_begin_epoch(void* handle, long rows_seen, const void* main_half, 
   MUSED_REQUIRE(h && rows_seen >= 0 && rows_seen % h->N == 0, "mused_swfd_begin_epoch: rows_seen must be a multiple of N");
   hipStream_t st = (hipStream_t)stream;
   const size_t S = h->S, L = h->L;
-  MUSED_CHECK_HIP(hipMemsetAsync(h->buf, 0, 8 * S * h->n2 * h->d, st));
+  MUSED_CHECK_HIP(hipMemsetAsync(h->buf, 0, 8 * S * (size_t)h->n2 * h->d, st));
   MUSED_CHECK_HIP(hipMemsetAsync(h->meta, 0, 4 * S * 4, st));
   MUSED_CHECK_HIP(hipMemsetAsync(h->dropped, 0, 8 * S, st));
   MUSED_CHECK_HIP(hipMemsetAsync(h->qt, 0, 8 * S * h->cap, st));
   (void)L;
   if (main_half) {
+    MUSED_REQUIRE(h->lanes == 1, "mused_swfd_begin_epoch: a state blob can only be imported into a single-lane handle");
     int rc = half_copy(h, 0, (char*)main_half, false, st);
     if (rc) return rc;
   }

@@ -52,7 +52,7 @@ class StreamPipeline:
         # (only when this pipeline has the GPU to itself: HIP maps streams onto a handful of hardware
         # queues -- 4 by default -- and streams sharing a queue run in order, so concurrent pipelines
         # use ONE stream each and overlap with each other instead)
-        self._side = torch.cuda.Stream() if (feature_sketch and stream is None) else None
+        self._side = torch.cuda.Stream(priority=-1) if (feature_sketch and stream is None) else None
         # all device work of this pipeline is enqueued on `stream` (default: the current stream), so
         # several pipelines -- each owning a contiguous block of windows -- can share one GPU
         self._stream = stream

@@ -29,14 +29,17 @@ _DT = {torch.float32: F32, torch.float64: F64, torch.int64: I64}
 
 
 class SeqBasedSWFD:
-    def __init__(self, N, R, d, sketch_dim, *, stage_rows: int = 1024, sweeps: int = 0, device="cuda"):
+    def __init__(self, N, R, d, sketch_dim, *, stage_rows: int = 1024, sweeps: int = 0, device="cuda", lanes: int = 1):
         _require_gpu()
         self.N, self.R, self.d, self.ell = int(N), float(R), int(d), int(sketch_dim)
         if self.N < 1 or self.d < 1 or self.ell < 1:
             raise ValueError("N, d and sketch_dim must be positive")
         self.device = device
         self._h = C.c_void_p()
-        call("mused_swfd_create", self.N, self.R, self.d, self.ell, int(sweeps), C.byref(self._h))
+        # lanes > 1: that many independent sketch sets (e.g. the windows of several contiguous blocks of
+        # the stream) advanced in lockstep by the same kernel launches -- `fit_lanes` / `get_device`
+        self.lanes = int(lanes)
+        call("mused_swfd_create_lanes", self.N, self.R, self.d, self.ell, int(sweeps), self.lanes, C.byref(self._h))
         self.L = _lib.lib().mused_swfd_levels(self._h)
         self._stage = np.empty((max(int(stage_rows), 1), self.d), dtype=np.float64)
         self._staged = 0
@@ -50,7 +53,21 @@ class SeqBasedSWFD:
             # stream, and torch's allocator reuses a block only in stream order.
             self._staged = 0
 
+    def fit_lanes(self, X: torch.Tensor):
+        """X: CUDA tensor (lanes, n, d) (any strides with unit stride along d): n rows for every lane."""
+        if X.dim() != 3 or X.shape[0] != self.lanes or X.shape[2] != self.d or not X.is_cuda:
+            raise ValueError(f"expected a CUDA tensor of shape ({self.lanes}, n, {self.d})")
+        if X.dtype not in _DT:
+            X = X.to(torch.float64)
+        if X.stride(2) != 1:
+            X = X.contiguous()
+        call("mused_swfd_append_lanes", self._h, ptr(X), _DT[X.dtype], X.shape[1], X.stride(1), X.stride(0), stream_ptr())
+        self._keepalive = X
+        return self
+
     def fit(self, X):
+        if self.lanes != 1:
+            raise ValueError("multi-lane sketch: use fit_lanes")
         if isinstance(X, torch.Tensor) and X.is_cuda:
             self._flush()
             t = X if X.dim() == 2 else X.reshape(1, -1)
@@ -82,9 +99,10 @@ class SeqBasedSWFD:
     def get_device(self):
         """(sketch (l, d), sigma (l,), info (2,) = [level, delta]) as fp64 CUDA tensors."""
         self._flush()
-        B = torch.empty((self.ell, self.d), dtype=torch.float64, device=self.device)
-        sig = torch.empty(self.ell, dtype=torch.float64, device=self.device)
-        info = torch.empty(2, dtype=torch.float64, device=self.device)
+        lead = () if self.lanes == 1 else (self.lanes,)
+        B = torch.empty(lead + (self.ell, self.d), dtype=torch.float64, device=self.device)
+        sig = torch.empty(lead + (self.ell,), dtype=torch.float64, device=self.device)
+        info = torch.empty(lead + (2,), dtype=torch.float64, device=self.device)
         call("mused_swfd_query", self._h, ptr(B), ptr(sig), ptr(info), stream_ptr())
         return B, sig, info
 
@@ -93,6 +111,8 @@ class SeqBasedSWFD:
         level used, delta of the final shrink); main.py:70 consumes element 0 only."""
         B, sig, info = self.get_device()
         info = info.cpu().numpy()
+        if self.lanes != 1:
+            return B.cpu().numpy(), sig.cpu().numpy(), info[:, 0].astype(int), info[:, 1]
         return B.cpu().numpy(), sig.cpu().numpy(), int(info[0]), float(info[1])
 
     # -- bookkeeping / multi-GPU state exchange ---------------------------------------------------

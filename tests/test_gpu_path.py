@@ -199,3 +199,30 @@ def test_swfd_state_exchange_between_ranks():
     assert np.array_equal(s1, s_seq) and np.array_equal(B1, B_seq)
     for o in (seq, r0, r1):
         o.close()
+
+
+def test_swfd_lanes_equal_independent_sketches():
+    """B lanes advanced in lockstep by shared launches == B separate sketch objects."""
+    from mused_amd import synth
+    from mused_amd.swfd import SeqBasedSWFD as Dev
+
+    N, ell, d, B = 300, 8, 48, 3
+    Xs = [synth.make_stream(kind, 2 * N + 50, d, 7 + i)[0] for i, kind in enumerate(["gauss", "blob", "fd"])]
+    R = max(float((x.astype(np.float64) ** 2).sum(1).max()) for x in Xs)
+    lanes = Dev(N=N, R=R, d=d, sketch_dim=ell, lanes=B)
+    singles = [Dev(N=N, R=R, d=d, sketch_dim=ell) for _ in range(B)]
+    X = torch.from_numpy(np.stack(Xs)).cuda()  # (B, n, d) float32
+    t = 0
+    for step in [130, 170, 1, 299, 50]:
+        lanes.fit_lanes(X[:, t : t + step])
+        for b in range(B):
+            singles[b].fit(X[b, t : t + step])
+        t += step
+        Bl, sl, ll, dl = lanes.get()
+        for b in range(B):
+            Bs, ss, ls, ds = singles[b].get()
+            assert int(ll[b]) == ls
+            assert np.array_equal(Bl[b], Bs) and np.array_equal(sl[b], ss) and dl[b] == ds
+    lanes.close()
+    for sk in singles:
+        sk.close()
