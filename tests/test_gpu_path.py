@@ -226,3 +226,54 @@ def test_swfd_lanes_equal_independent_sketches():
     lanes.close()
     for sk in singles:
         sk.close()
+
+
+# ---------------------------------------------------------------- BASELINE config-2 full size ----
+@pytest.mark.parametrize("name", ["c2_blob_s0", "c2_gauss_s0"])
+def test_full_size_window_matches_reference_golden(name):
+    """W = 10,000, d = 1024, l = 128, k = 50 (BASELINE.json configs[1]): neighbour hash, R, the 128
+    singular values, embedding samples and the 10,000 k-means labels of the REFERENCE reproduced."""
+    from mused_amd import matrix_operations as mo
+    from mused_amd.engine import WindowEngine
+
+    g = load_golden(name)
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    eng = WindowEngine(W)
+    adj = eng.knn_adjacency(torch.from_numpy(mods[0]).cuda(), k, "l2")
+    assert nbr_hash(_bool_from_adj(adj)) == str(g["w0_adj_hash"][0])
+    fused = eng.fuse([adj])
+    assert eng.max_row_sq_norm(fused) == pytest.approx(float(g["w0_R"]), rel=1e-12)
+    emb, sig = eng.svd_reduce(fused, ell, seed, nnz_cap=W * k)
+    assert eng.rsvd_status()[0] == 0
+    emb, sig = emb.cpu().numpy(), sig.cpu().numpy()
+    np.testing.assert_allclose(sig, g["w0_sigma"], rtol=1e-8)  # north star: 1e-4 rel
+    rows = g["w0_emb_rows"]
+    np.testing.assert_allclose(emb[rows], g["w0_emb_sample"], atol=1e-7 * np.abs(g["w0_emb_sample"]).max())
+    km = mo.perform_clustering(emb, len(np.unique(labels)), seed)
+    assert np.array_equal(km.astype(np.int32), g["w0_kmeans_labels"])  # bit-exact event indices
+    eng.close()
+
+
+def test_full_size_swfd_properties():
+    """d = 1024, l = 128, N = 10,000 (config 2): covariance error bound against the exact window Gram
+    (computed on the device), orthogonal sketch rows, and the sketch forgets an expired window."""
+    from mused_amd import synth
+    from mused_amd.swfd import SeqBasedSWFD as Dev
+
+    W, d, ell = 10000, 1024, 128
+    Xs = [torch.from_numpy(synth.stream_window("blob", t, W, d, 0)[0]).cuda() for t in range(2)]
+    R = float((Xs[0].double() ** 2).sum(1).max().item())
+    sk = Dev(N=W, R=R, d=d, sketch_dim=ell)
+    for t in range(2):
+        sk.fit(Xs[t])
+        B, sig, info = sk.get_device()
+        A = Xs[t].double()
+        E = A.t() @ A - B.t() @ B
+        err = torch.linalg.matrix_norm(E, ord=2).item()
+        f2 = (A * A).sum().item()
+        assert err <= 1.0 * f2 / ell, (t, err, f2 / ell)  # same bound as the oracle property test
+        Gs = B @ B.t()
+        off = (Gs - torch.diag(torch.diag(Gs))).abs().max().item()
+        assert off <= 1e-8 * Gs.max().item()
+        assert torch.allclose(sig, B.norm(dim=1), rtol=1e-12)
+    sk.close()

@@ -1,0 +1,112 @@
+"""End-to-end on the GPU: the window loop (main.py:13-130 role) and the NumPy drop-in call surface."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, regen_inputs
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize(
+    "name", ["c1_stream_blob_s0", "c1_stream_blob_s1", "c1_stream_gauss_s0", "c4s_stream_twomod_s0"]
+)
+@pytest.mark.parametrize("async_labels", [True, False])
+def test_stream_event_labels_bit_exact(name, async_labels):
+    """Whole-run `all_clusters` of the reference (approach sSVDMC) reproduced bit for bit by the device
+    pipeline, one and two modalities, with and without the asynchronous label worker."""
+    from mused_amd.pipeline import StreamPipeline
+
+    g = load_golden(name)
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    pipe = StreamPipeline(W, ell, k, seed, "sSVDMC", async_labels=async_labels)
+    out = pipe.run(mods, labels)
+    pipe.close()
+    assert np.array_equal(out.astype(np.int64), g["all_clusters"])
+    assert hashlib.sha256(out.astype(np.int64).tobytes()).hexdigest() == str(g["labels_sha"])
+
+
+def test_process_streaming_data_signature_and_hopping_windows():
+    """Same positional parameters as main.py:13; step_window_ratio = 2 (hopping windows, main.py:32)
+    against the oracle's window loop."""
+    from mused_amd import synth
+    from mused_amd.pipeline import process_streaming_data
+    from oracle import mo_oracle as omo
+
+    X, labels = synth.blob_stream(1200, 24, 2, n_centres=3)
+    res = process_streaming_data({}, [X.astype(np.float64)], [""], 400, 8, 20, 3, 0, "sSVDMC", labels, 2, 0.0, "types", False, 1.5, 2)
+    ref = omo.process_streaming_data([X.astype(np.float64)], [""], 400, 8, 20, 0, "sSVDMC", labels, step_window_ratio=2)
+    assert len(ref) == 5 * 400  # triggers at rows 400, 600, ..., 1200
+    assert np.array_equal(res["all_clusters"], ref)
+    assert res["processing_time"] > 0
+
+
+def test_swfdmc_approach_matches_oracle_pipeline():
+    """approach SWFDMC (main.py:58-76): SWFD over the rows of the fused matrix (d = W), R from the first
+    window only, sketch transposed to (W, l), labels equal to the CPU oracle pipeline."""
+    from mused_amd import synth
+    from mused_amd.pipeline import StreamPipeline
+    from oracle import mo_oracle as omo
+    from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
+
+    mods, labels = synth.two_modality_blob_stream(3 * 256, 16, 5, n_centres=3)
+    trace = []
+    ref = omo.process_streaming_data([m.astype(np.float64) for m in mods], ["", ""], 256, 6, 12, 0, "SWFDMC", labels,
+                                     swfd_cls=OraSWFD, trace=trace)
+    pipe = StreamPipeline(256, 6, 12, 0, "SWFDMC", async_labels=False)
+    out = pipe.run(mods, labels)
+    for a, b in zip(pipe.trace, trace):
+        np.testing.assert_allclose(a["sigma"], b["sigma"], rtol=0, atol=1e-8 * b["sigma"][0])
+    pipe.close()
+    assert np.array_equal(out, ref)
+
+
+def test_numpy_dropin_call_surface():
+    """`import matrix_operations` / `from swfd import SeqBasedSWFD` via mused_amd/compat, NumPy in/out."""
+    from conftest import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "mused_amd", "compat"))
+    try:
+        import matrix_operations as mo  # the drop-in, NOT the reference (which is not on sys.path here)
+        from swfd import SeqBasedSWFD
+
+        assert "mused_amd" in mo.create_adjacency_matrix.__module__
+        g = load_golden("edges")
+        A = mo.create_adjacency_matrix(g["nonfinite_X"], "", 5)  # non-finite rows dropped
+        assert A.dtype == np.float64 and np.array_equal(A.astype(np.uint8), g["nonfinite_A"])
+        X = g["k1_X"]
+        assert np.array_equal(mo.create_adjacency_matrix(X, "", 1).astype(np.uint8), g["k1_A"])
+        assert np.array_equal(mo.create_adjacency_matrix(X, "", 0).astype(np.uint8), g["k0_A"])
+        assert np.array_equal(mo.create_adjacency_matrix(X, "", 12).astype(np.uint8), g["kn_A"])
+        with pytest.raises(ValueError):
+            mo.create_adjacency_matrix(X, "", 13)
+        A1, A2 = g["fuse_A1"].astype(np.float64), g["fuse_A2"].astype(np.float64)
+        F2 = mo.fuse_matrices([A1, A2])
+        assert str(F2.dtype) == str(g["fuse2_dtype"]) and np.array_equal(F2.astype(np.uint8), g["fuse2"])
+        F1 = mo.fuse_matrices([A1])
+        assert str(F1.dtype) == str(g["fuse1_dtype"]) and np.array_equal(F1, A1)
+        with pytest.raises(NotImplementedError):
+            mo.perform_svd_reduction(np.full((4, 4), 0.5), 2, 0)
+        sk = SeqBasedSWFD(N=8, R=1.0, d=8, sketch_dim=2)  # main.py:62 keywords, demo sizes
+        out = sk.get()
+        assert len(out) == 4 and out[0].shape == (2, 8) and not out[0].any()
+        rng = np.random.default_rng(0)
+        for _ in range(20):
+            sk.fit(rng.integers(0, 2, size=(1, 8)))
+        assert sk.get()[0].shape == (2, 8)
+        with pytest.raises(ValueError):
+            sk.fit(np.zeros((1, 7)))
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("matrix_operations", None)
+        sys.modules.pop("swfd", None)
