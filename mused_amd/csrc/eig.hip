@@ -25,6 +25,7 @@ struct EigPlan {
   int ldn;     // OSJ: padded order (multiple of 64) = threads per workgroup
   double* Gc;  // OSJ: batch x ldn x ldn, column-major working copy
   double* lam; // OSJ: batch x ldn column norms
+  int* notconv;  // OSJ: sweeps x batch convergence flags
   double* G[2];
   double* V[2];
   hipGraph_t graph;
@@ -329,7 +330,11 @@ __host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
 
 template <int CB, int NT, int MODE, int DBG = 0>
 __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
-                                                      double* __restrict__ conv) {
+                                                      int* __restrict__ notconv, int sweep) {
+  // ADAPTIVE SWEEPS: notconv[sweep * batch + matrix] is set by any workgroup that met, in this sweep, a
+  // column pair with cos^2 > 1e-16; a matrix whose previous sweep set nothing is converged (that sweep
+  // left every cosine below ~1e-16 by quadratic convergence) and its workgroups return at once.
+  if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;
   // MODE 1: block pair (bp, bq) of the round-robin, cross pairs only; MODE 2: ONE block of 2*CB
   // consecutive columns (blockIdx.x), all pairs inside it; MODE 0: block pair, all pairs.
   // DBG != 0: timing-only ablations (results are wrong): 2 no rotation maths, 3 no barrier, 4 no apply.
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
   }
   const int r = threadIdx.x, lane = r & 63, wave = r >> 6;
   double x[C2];
+  int active = 0;
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
     x[j] = M[(long)(bp * CB + j) * ldn + r];
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
       }
       const double dp = dsc[wave][p], dq = dsc[wave][q];
       const double pq = raw * dp * dq;
+      active |= (pq * pq > 1e-16 * (nrm[wave][p] * nrm[wave][q]));
       double c = 1.0, s = 0.0, npp, nqq;
       if constexpr (DBG == 2) {
         c = 0.8; s = 0.6; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
     const int col = (pos < CB) ? (bp * CB + pos) : (bq * CB + pos - CB);
     M[(long)col * ldn + r] = x[j] * dsc[wave][j];
   }
-  (void)conv;
+  if (notconv && wave == 0 && __any(active) && lane == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
   (void)n;
 }
 
@@ -511,7 +518,7 @@ __global__ void osj_extract_kernel(const double* __restrict__ Gc, const double* 
 }
 
 template <int NT>
-static void osj_launch_sweep(EigPlan* p, hipStream_t st) {
+static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   // one sweep = every column pair exactly once: one INTRA launch (pairs inside each group of 2*CB
   // columns... i.e. inside each block pair (2b, 2b+1)) followed by the block-pair rounds; the pair
   // (2b, 2b+1) itself meets in the round-robin too, where only its CROSS pairs are left to do.
@@ -520,27 +527,27 @@ static void osj_launch_sweep(EigPlan* p, hipStream_t st) {
   // rotate the cross pairs of (2b, 2b+1); instead launch MODE 2 with half-size blocks: CB/2 columns per
   // block -> 2*(CB/2) = CB columns per workgroup = exactly one block.
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, (double*)nullptr);
+                     2 * nb, 0, p->notconv, sweep);
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, NT, 1>), dim3(nb / 2, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                       nb, round, (double*)nullptr);
+                       nb, round, p->notconv, sweep);
 }
 
 static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
   for (int sw = 0; sw < p->sweeps; ++sw) {
     switch (p->ldn) {
-      case 64: osj_launch_sweep<64>(p, st); break;
-      case 128: osj_launch_sweep<128>(p, st); break;
-      case 192: osj_launch_sweep<192>(p, st); break;
-      case 256: osj_launch_sweep<256>(p, st); break;
-      case 320: osj_launch_sweep<320>(p, st); break;
-      case 384: osj_launch_sweep<384>(p, st); break;
-      case 448: osj_launch_sweep<448>(p, st); break;
-      case 512: osj_launch_sweep<512>(p, st); break;
-      case 640: osj_launch_sweep<640>(p, st); break;
-      case 768: osj_launch_sweep<768>(p, st); break;
-      case 896: osj_launch_sweep<896>(p, st); break;
-      case 1024: osj_launch_sweep<1024>(p, st); break;
+      case 64: osj_launch_sweep<64>(p, sw, st); break;
+      case 128: osj_launch_sweep<128>(p, sw, st); break;
+      case 192: osj_launch_sweep<192>(p, sw, st); break;
+      case 256: osj_launch_sweep<256>(p, sw, st); break;
+      case 320: osj_launch_sweep<320>(p, sw, st); break;
+      case 384: osj_launch_sweep<384>(p, sw, st); break;
+      case 448: osj_launch_sweep<448>(p, sw, st); break;
+      case 512: osj_launch_sweep<512>(p, sw, st); break;
+      case 640: osj_launch_sweep<640>(p, sw, st); break;
+      case 768: osj_launch_sweep<768>(p, sw, st); break;
+      case 896: osj_launch_sweep<896>(p, sw, st); break;
+      case 1024: osj_launch_sweep<1024>(p, sw, st); break;
       default: set_error("osj: unsupported padded order %d", p->ldn); return MUSED_ERR_UNSUPPORTED;
     }
   }
@@ -582,6 +589,11 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
     MUSED_CHECK_HIP(hipMalloc(&p->G[0], bytes));
     MUSED_CHECK_HIP(hipMalloc(&p->Gc, sizeof(double) * (size_t)batch * p->ldn * p->ldn));
     MUSED_CHECK_HIP(hipMalloc(&p->lam, sizeof(double) * (size_t)batch * p->ldn));
+    // Adaptive sweep count (off by default): the all-pairs criterion also waits for the smallest
+    // eigen-directions, which the path never uses, and costs more sweeps than the fixed count that is
+    // enough for the upper half of the spectrum.  MUSED_EIG_ADAPTIVE=1 turns it on.
+    const char* ad = getenv("MUSED_EIG_ADAPTIVE");
+    if (ad && ad[0] == '1') MUSED_CHECK_HIP(hipMalloc(&p->notconv, sizeof(int) * (size_t)batch * (sweeps + 1)));
   } else {
     for (int i = 0; i < 2; ++i) {
       MUSED_CHECK_HIP(hipMalloc(&p->G[i], bytes));
@@ -619,6 +631,7 @@ void eig_plan_destroy(EigPlan* p) {
   }
   if (p->Gc) (void)hipFree(p->Gc);
   if (p->lam) (void)hipFree(p->lam);
+  if (p->notconv) (void)hipFree(p->notconv);
   delete p;
 }
 
@@ -628,6 +641,10 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
   if (p->method == 1) {
     const long per = (long)p->ldn * p->ldn;
     hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc);
+    if (p->notconv) {
+      int zrc = zero_ints(p->notconv, (long)p->batch * (p->sweeps + 1), st);
+      if (zrc) return zrc;
+    }
     if (p->have_graph && allow_graph) {
       MUSED_CHECK_HIP(hipGraphLaunch(p->exec, st));
     } else {
@@ -682,12 +699,12 @@ int mused_debug_osj_time(const double* init, int batch, int variant, int reps, d
   auto launch = [&](int round) {
     dim3 grid(nb / 2, batch), blk(256);
     switch (variant) {
-      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
-      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
-      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
-      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
-      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr); break;
-      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (double*)nullptr);
+      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
+      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
+      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
+      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
+      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
+      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0);
     }
   };
   MUSED_CHECK_HIP(hipEventRecord(e0, st));
