@@ -281,6 +281,13 @@ def main():
         # ---- roofline of the dominant kernel (measured live with HIP events above) ----
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
         gemm_s = stages["scores_gemm_ms"] * 1e-3
+        traffic = None
+        try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), config 2 only
+            if args.workload == "c2":
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_scores.json")))
+                traffic = pm["traffic_bytes_per_launch_lower"]
+        except Exception:
+            traffic = None
         roof = {
             "kernel": "gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64)",
             "bound": "mfma",
@@ -288,7 +295,8 @@ def main():
             "peak": 78.6,
             "unit": "TFLOP/s",
             "frac": flops / gemm_s / 1e12 / 78.6,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": "FETCH_SIZE + WRITE_SIZE of rocprofv3 --pmc passes (profiles/r01_pmc_scores.json), bytes per launch",
             "launch_ms": stages["scores_gemm_ms"],
             "algorithmic_flops_per_launch": flops,
         }
