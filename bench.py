@@ -179,14 +179,20 @@ def main():
     # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
     # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
     B = max(1, min(args.lanes, K))
-    while K % B:
-        B -= 1
-    blk = K // B
-    T = Wu + blk                      # windows per lane
-    per_rank = B * T
+    blks = [K // B + (1 if p < K % B else 0) for p in range(B)]   # timed windows per lane
+    blk = max(blks)
+    T = Wu + blk                      # lock-step groups (a lane with fewer windows repeats its last one: padding)
+    per_rank = K + B * Wu
     first = rank * per_rank           # global window index of lane 0, window 0
-    host = [[synth.stream_window(args.kind, first + p * T + t, W, d, args.seed) for t in range(T)] for p in range(B)]
-    rows_all = torch.from_numpy(np.stack([np.stack([x for x, _ in hp]) for hp in host])).cuda()  # (B, T, W, d) resident
+    bases, b0 = [], first
+    for p in range(B):
+        bases.append(b0)
+        b0 += Wu + blks[p]
+    host = [[synth.stream_window(args.kind, bases[p] + t, W, d, args.seed) for t in range(Wu + blks[p])] for p in range(B)]
+    rows_all = torch.empty((B, T, W, d), dtype=torch.float32, device="cuda")   # resident before timing
+    for p in range(B):
+        for t in range(T):
+            rows_all[p, t].copy_(torch.from_numpy(host[p][min(t, Wu + blks[p] - 1)][0]))
     labels = [[l for _, l in hp] for hp in host]
 
     sketch = None
@@ -233,7 +239,8 @@ def main():
         torch.cuda.set_device(local_rank)
         for t in range(lo, hi):
             for p in range(B):
-                pipe.process_window([rows_all[p, t]], labels[p][t], trigger=(first + p * T + t + 1) * W - 1)
+                if t < Wu + blks[p]:
+                    pipe.process_window([rows_all[p, t]], labels[p][t], trigger=(bases[p] + t + 1) * W - 1)
         pipe.flush()
 
     def run_range(lo, hi):
@@ -263,8 +270,9 @@ def main():
 
     # label chain across ranks (outside the timed region: W ints per window)
     # traces were appended in (t, lane) order; the stream order is lane-major
-    timed = pipe.trace[Wu * B:]
-    raw_local = np.array([timed[(t * B) + p]["raw"] for p in range(B) for t in range(blk)], dtype=np.int64)
+    by_trigger = {tr["trigger"]: tr["raw"] for tr in pipe.trace}
+    raw_local = np.array([by_trigger[(bases[p] + t + 1) * W - 1] for p in range(B) for t in range(Wu, Wu + blks[p])],
+                         dtype=np.int64)
     counts = [K] * world
     raw_all = mdist.gather_raw_labels(raw_local, counts, device="cuda")
     all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
@@ -275,8 +283,8 @@ def main():
             # a window is done when its labels AND its sketch are: take the later one.  Sketch group t
             # completes at t_ref + elapsed(ref event -> its event); latency counts from its enqueue.
             sk_done = {t: ref["t"] + ref["ev"].elapsed_time(sk_events[t][0]) * 1e-3 for t in range(Wu, T)}
-            sk_lat = np.array([sk_done[t] - sk_events[t][1] for t in range(Wu, T) for _ in range(B)])
-            lat = np.maximum(lat, sk_lat[: len(lat)]) if len(lat) == len(sk_lat) else lat
+            sk_lat = np.array([sk_done[t] - sk_events[t][1] for t in range(Wu, T) for p in range(B) if t < Wu + blks[p]])
+            lat = np.maximum(lat, sk_lat) if len(lat) == len(sk_lat) else lat
         stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all)
         # ---- roofline of the dominant kernel (measured live with HIP events above) ----
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch

@@ -277,3 +277,31 @@ def test_full_size_swfd_properties():
         assert off <= 1e-8 * Gs.max().item()
         assert torch.allclose(sig, B.norm(dim=1), rtol=1e-12)
     sk.close()
+
+
+def test_config3_shapes_l256():
+    """BASELINE config 3 uses l = 256: the 512- and 1024-order eigenproblems of the sketch and the 266-column
+    panels of the eigenstep, at a window small enough for the CPU oracle."""
+    from mused_amd import synth
+    from mused_amd.engine import WindowEngine
+    from oracle import mo_oracle as omo
+
+    N, ell, d = 700, 256, 320
+    X, _ = synth.make_stream("blob", N + 300, d, 11)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    dev, ora = _swfd_pair(N, R, d, ell)
+    for lo, hi in [(0, 300), (300, 700), (700, 1000)]:
+        dev.fit(X[lo:hi])
+        ora.fit(X[lo:hi])
+        _compare(dev, ora, f"l=256 t={hi}")
+    dev.close()
+    # eigenstep with reduced_dim = 256 on a 1500-row window (r = 266 random columns)
+    Xw, _ = synth.blob_stream(1500, 96, 3, n_centres=6)
+    eng = WindowEngine(1500)
+    adj = eng.knn_adjacency(torch.from_numpy(Xw).cuda(), 40)
+    emb, sig = eng.svd_reduce(adj, 256, 0, nnz_cap=1500 * 40)
+    A = omo.create_adjacency_matrix(Xw, "", 40)
+    e_ref, s_ref, _ = omo.randomized_svd_reduce(A, 256, 0)
+    np.testing.assert_allclose(sig.cpu().numpy(), s_ref, rtol=1e-8)
+    np.testing.assert_allclose(emb.cpu().numpy(), e_ref, atol=1e-6 * np.abs(e_ref).max())
+    eng.close()
