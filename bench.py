@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
-    ap.add_argument("--lanes", type=int, default=4,
+    ap.add_argument("--lanes", type=int, default=8,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
                          "launches (1 = strictly one window at a time)")
     return ap.parse_args()
@@ -178,7 +178,10 @@ def main():
     # (mused_swfd_*_lanes) on one HIP stream / host thread; adjacency + eigenstep + labels of the same
     # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
     # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
-    B = max(1, min(args.lanes, K))
+    # lanes: at most --lanes; the count that minimises (lock-step groups) x (measured time of a group of B
+    # lanes at config 2: about 290 + 95 B ms -- latency-bound, so wide groups are cheap)
+    cand = range(1, max(1, min(args.lanes, K)) + 1)
+    B = min(cand, key=lambda b: (-(-K // b)) * (290.0 + 95.0 * b))
     blks = [K // B + (1 if p < K % B else 0) for p in range(B)]   # timed windows per lane
     blk = max(blks)
     T = Wu + blk                      # lock-step groups (a lane with fewer windows repeats its last one: padding)
@@ -252,6 +255,9 @@ def main():
 
     run_range(0, Wu)
     n_warm_lat = len(pipe.latencies)
+    pipe.eng.score_events = []  # HIP events around every similarity-GEMM launch of the timed region
+    if sketch is not None:
+        sketch.profile(True)    # HIP events around every Jacobi sweep graph of the timed region
 
     if world > 1:
         dist.barrier()
@@ -285,10 +291,48 @@ def main():
             sk_done = {t: ref["t"] + ref["ev"].elapsed_time(sk_events[t][0]) * 1e-3 for t in range(Wu, T)}
             sk_lat = np.array([sk_done[t] - sk_events[t][1] for t in range(Wu, T) for p in range(B) if t < Wu + blks[p]])
             lat = np.maximum(lat, sk_lat) if len(lat) == len(sk_lat) else lat
+        ev_pairs = pipe.eng.score_events
+        pipe.eng.score_events = None
+        gemm_live_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None
         stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all)
-        # ---- roofline of the dominant kernel (measured live with HIP events above) ----
+        stages["scores_gemm_ms_live_timed_region"] = gemm_live_ms
+        # ---- rooflines (both measured live with HIP events on the launch streams over the timed region) ----
+        # (1) dominant kernel by time: osj_round_kernel, one round of the one-sided block Jacobi of the FD
+        #     rotation.  Per launch it streams every Gram matrix of the batch from memory and back
+        #     (16 n^2 B per matrix): HBM/Infinity-Cache bound load/store phases around a
+        #     latency-bound chain of 32 dependent pair-steps.
+        roof = None
+        if sketch is not None:
+            osj_ms, osj_launches, osj_bytes = sketch.profile_read()
+            sketch.profile(False)
+            if osj_launches:
+                osj_us = 1e3 * osj_ms / osj_launches
+                gbs = osj_bytes / (osj_us * 1e-6) / 1e9
+                tr = None
+                try:
+                    if args.workload == "c2":
+                        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_osj.json")))
+                        if pm.get("lanes") == B:
+                            tr = pm["traffic_bytes_per_launch"]
+                except Exception:
+                    tr = None
+                roof = {
+                    "kernel": f"osj_round_kernel<32,256> (one-sided block Jacobi round of the FD rotation, "
+                              f"{sketch.lanes * 2 * sketch.L} Gram matrices of order {2 * ell} per launch)",
+                    "bound": "hbm",
+                    "achieved": gbs,
+                    "peak": 8000.0,
+                    "unit": "GB/s",
+                    "frac": gbs / 8000.0,
+                    "traffic": tr,
+                    "launch_us": osj_us,
+                    "launches_timed": osj_launches,
+                    "algorithmic_bytes_per_launch": osj_bytes,
+                }
+        # (2) the contraction kernel: similarity GEMM X X^T on fp64 MFMA
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
-        gemm_s = stages["scores_gemm_ms"] * 1e-3
+        gemm_ms = gemm_live_ms if gemm_live_ms else stages["scores_gemm_ms"]
+        gemm_s = gemm_ms * 1e-3
         traffic = None
         try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), config 2 only
             if args.workload == "c2":
@@ -296,7 +340,7 @@ def main():
                 traffic = pm["traffic_bytes_per_launch_lower"]
         except Exception:
             traffic = None
-        roof = {
+        roof_gemm = {
             "kernel": "gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64)",
             "bound": "mfma",
             "achieved": flops / gemm_s / 1e12,
@@ -304,10 +348,12 @@ def main():
             "unit": "TFLOP/s",
             "frac": flops / gemm_s / 1e12 / 78.6,
             "traffic": traffic,
-            "traffic_note": "FETCH_SIZE + WRITE_SIZE of rocprofv3 --pmc passes (profiles/r01_pmc_scores.json), bytes per launch",
-            "launch_ms": stages["scores_gemm_ms"],
+            "launch_ms": gemm_ms,
+            "launch_ms_standalone": stages["scores_gemm_ms"],
             "algorithmic_flops_per_launch": flops,
         }
+        if roof is None:
+            roof = roof_gemm
         res = {
             "metric": "stream rows/sec, d=1024 l=128 window=10k synthetic (SWFD + kNN similarity + eigenstep + labels)",
             "value": world * K * W / elapsed,
@@ -333,6 +379,7 @@ def main():
             "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
             "stages_ms": stages,
             "roofline": roof,
+            "roofline_mfma": roof_gemm,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.kind, args.seed, with_swfd=not args.no_swfd)

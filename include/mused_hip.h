@@ -121,6 +121,10 @@ int mused_swfd_append_lanes(void* handle, const void* rows, int dtype, long n_ro
                             void* stream);
 int mused_swfd_destroy(void* handle);
 int mused_swfd_levels(void* handle);
+/* live timing of the rotation eigensolver: HIP events around every Jacobi sweep graph; read is BLOCKING and
+ * returns summed ms, number of osj_round_kernel launches covered, bytes one launch streams (HOST outputs) */
+int mused_swfd_profile(void* handle, int on);
+int mused_swfd_profile_read(void* handle, double* total_ms, long* launches, double* bytes_per_launch);
 /* .fit(row) for n_rows rows at once (any batching gives the same sketch) */
 int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, long ld, void* stream);
 /* .get(): out_sketch (lanes x sketch_dim x d), out_sigma (lanes x sketch_dim, may be NULL),

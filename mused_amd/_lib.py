@@ -56,6 +56,8 @@ _PROTOS = {
     "mused_swfd_append_lanes": (_i, [_vp, _vp, _i, _l, _l, _l, _vp]),
     "mused_swfd_destroy": (_i, [_vp]),
     "mused_swfd_levels": (_i, [_vp]),
+    "mused_swfd_profile": (_i, [_vp, _i]),
+    "mused_swfd_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
     "mused_swfd_append": (_i, [_vp, _vp, _i, _l, _l, _vp]),
     "mused_swfd_query": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mused_swfd_counters": (_i, [_vp, C.POINTER(_l), C.POINTER(_i)]),

@@ -26,6 +26,11 @@ struct EigPlan {
   double* Gc;  // OSJ: batch x ldn x ldn, column-major working copy
   double* lam; // OSJ: batch x ldn column norms
   int* notconv;  // OSJ: sweeps x batch convergence flags
+  // live profiling (off by default): HIP events around every replay of the sweep graph
+  bool prof;
+  int prof_n;
+  std::vector<hipEvent_t>* ev0;
+  std::vector<hipEvent_t>* ev1;
   double* G[2];
   double* V[2];
   hipGraph_t graph;
@@ -632,10 +637,52 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->Gc) (void)hipFree(p->Gc);
   if (p->lam) (void)hipFree(p->lam);
   if (p->notconv) (void)hipFree(p->notconv);
+  if (p->ev0) {
+    for (size_t i = 0; i < p->ev0->size(); ++i) {
+      (void)hipEventDestroy((*p->ev0)[i]);
+      (void)hipEventDestroy((*p->ev1)[i]);
+    }
+    delete p->ev0;
+    delete p->ev1;
+  }
   delete p;
 }
 
 double* eig_plan_input(EigPlan* p) { return p->G[0]; }
+
+// Live timing of the Jacobi sweeps: between enable and read every replay of the sweep graph is bracketed
+// by HIP events on the launch stream.  Read (blocking) returns the summed duration, the number of
+// osj_round_kernel launches it covers and the bytes one launch moves (every matrix element read once
+// and written once).
+int eig_plan_profile(EigPlan* p, bool on) {
+  if (!p || p->method != 1) return MUSED_OK;
+  if (on && !p->ev0) {
+    p->ev0 = new std::vector<hipEvent_t>(2048);
+    p->ev1 = new std::vector<hipEvent_t>(2048);
+    for (size_t i = 0; i < p->ev0->size(); ++i) {
+      MUSED_CHECK_HIP(hipEventCreate(&(*p->ev0)[i]));
+      MUSED_CHECK_HIP(hipEventCreate(&(*p->ev1)[i]));
+    }
+  }
+  p->prof = on;
+  if (on) p->prof_n = 0;
+  return MUSED_OK;
+}
+
+int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* bytes_per_launch) {
+  *total_ms = 0.0; *launches = 0; *bytes_per_launch = 0.0;
+  if (!p || p->method != 1 || !p->ev0) return MUSED_OK;
+  for (int i = 0; i < p->prof_n; ++i) {
+    MUSED_CHECK_HIP(hipEventSynchronize((*p->ev1)[i]));
+    float ms = 0.f;
+    MUSED_CHECK_HIP(hipEventElapsedTime(&ms, (*p->ev0)[i], (*p->ev1)[i]));
+    *total_ms += ms;
+  }
+  const int nb = p->ldn / OSJ_CB;
+  *launches = (long)p->prof_n * p->sweeps * nb;  // per sweep: 1 intra launch + (nb - 1) block-pair rounds
+  *bytes_per_launch = 16.0 * (double)p->batch * p->ldn * p->ldn;
+  return MUSED_OK;
+}
 
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, bool allow_graph) {
   if (p->method == 1) {
@@ -645,11 +692,17 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
       int zrc = zero_ints(p->notconv, (long)p->batch * (p->sweeps + 1), st);
       if (zrc) return zrc;
     }
+    const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
+    if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->have_graph && allow_graph) {
       MUSED_CHECK_HIP(hipGraphLaunch(p->exec, st));
     } else {
       const int rc = osj_enqueue_sweeps(p, st);
       if (rc) return rc;
+    }
+    if (rec) {
+      MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
+      ++p->prof_n;
     }
     hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam);
     hipLaunchKernelGGL(osj_extract_kernel, dim3(cdiv((long)p->n * p->n, 256), p->batch), dim3(256), 0, st, p->Gc, p->lam,

@@ -43,6 +43,8 @@ void eig_plan_destroy(EigPlan* p);
 // In: G (batch x n x n, symmetric) is copied into the plan's workspace.  Out: eigenvalues
 // (unsorted, batch x n) and eigenvectors V (batch x n x n, column j <-> eigenvalue j).
 int eig_plan_run(EigPlan* p, const double* G, double* evals, double* V, hipStream_t stream);
+int eig_plan_profile(EigPlan* p, bool on);
+int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* bytes_per_launch);
 double* eig_plan_input(EigPlan* p);  // (batch x n x n) device buffer the caller may fill directly
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t stream, bool allow_graph);
 

@@ -481,6 +481,21 @@ int mused_swfd_destroy(void* handle) {
 
 int mused_swfd_levels(void* handle) { return handle ? ((Swfd*)handle)->L : -1; }
 
+// Live timing of the rotation eigensolver (the dominant kernel of the path): enable, run appends, then read
+// (BLOCKING) the summed duration of the Jacobi sweep graphs, the number of osj_round_kernel launches in
+// them and the bytes one launch streams (all S matrices of order 2l read once and written once).
+int mused_swfd_profile(void* handle, int on) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h, "mused_swfd_profile: null handle");
+  return eig_plan_profile(h->eig, on != 0);
+}
+
+int mused_swfd_profile_read(void* handle, double* total_ms, long* launches, double* bytes_per_launch) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && total_ms && launches && bytes_per_launch, "mused_swfd_profile_read: null pointer");
+  return eig_plan_profile_read(h->eig, total_ms, launches, bytes_per_launch);
+}
+
 // Replaces the per-row SeqBasedSWFD.fit(row) loop (main.py:65-67): appends n_rows rows of
 // length d (device pointer, row pitch ld elements, dtype MUSED_F32 / F64 / I64 -- the fused matrix
 // is int64 for >= 2 modalities, matrix_operations.py:138).  Any split of the stream into calls

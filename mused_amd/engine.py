@@ -135,6 +135,9 @@ class WindowEngine:
         self._rsvd_key = None
         self._rsvd_cap = 0
         self._q0_key = None
+        # optional live timing: set to a list and every score-GEMM launch is bracketed by HIP events
+        # recorded on the launch stream -> [(start_event, end_event), ...]
+        self.score_events = None
 
     # ---- a1 / a2 ------------------------------------------------------------------------
     def knn_adjacency(self, rows, k: int, metric: str = "l2", want_idx: bool = False):
@@ -160,10 +163,16 @@ class WindowEngine:
         w = words_for(n)
         mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
         idx = torch.empty((n, kk), dtype=torch.int32, device=self.device) if want_idx else None
-        call(
-            "mused_knn_topk", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(self.scores), ptr(self.norms),
-            ptr(idx) if want_idx else None, ptr(mask), w, stream_ptr(),
-        )
+        if self.score_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("mused_pairwise_scores", ptr(X), _DT[X.dtype], n, d, X.stride(0), m, ptr(self.norms), ptr(self.scores),
+             stream_ptr())
+        if self.score_events is not None:
+            e1.record()
+            self.score_events.append((e0, e1))
+        call("mused_select_k_smallest", ptr(self.scores), n, n, kk, ptr(idx) if want_idx else None, ptr(mask), w,
+             stream_ptr())
         adj = Adjacency(mask, n)
         return (adj, idx) if want_idx else adj
 

@@ -115,6 +115,16 @@ class SeqBasedSWFD:
             return B.cpu().numpy(), sig.cpu().numpy(), info[:, 0].astype(int), info[:, 1]
         return B.cpu().numpy(), sig.cpu().numpy(), int(info[0]), float(info[1])
 
+    # -- live timing of the rotation eigensolver ----------------------------------------------------
+    def profile(self, on: bool):
+        call("mused_swfd_profile", self._h, 1 if on else 0)
+
+    def profile_read(self):
+        """(summed ms of the Jacobi sweep graphs, osj_round_kernel launches covered, bytes per launch)."""
+        ms, n, b = C.c_double(), C.c_long(), C.c_double()
+        call("mused_swfd_profile_read", self._h, C.byref(ms), C.byref(n), C.byref(b))
+        return ms.value, n.value, b.value
+
     # -- bookkeeping / multi-GPU state exchange ---------------------------------------------------
     @property
     def rows_seen(self) -> int:
