@@ -59,6 +59,7 @@ class StreamPipeline:
         # pinned staging buffers are recycled: allocating pinned memory synchronises the device, which
         # would serialise concurrent pipelines
         self._pins = []
+        self._device = torch.cuda.current_device()  # worker threads must select it themselves
 
     # ---- device side of one window --------------------------------------------------------------
     def window_device(self, mods):
@@ -109,6 +110,7 @@ class StreamPipeline:
 
     def _finish(self, job):
         ev, red_pin, sig_pin, n_clusters, trigger, t_start = job
+        torch.cuda.set_device(self._device)
         ev.synchronize()
         self._labels(red_pin.numpy().copy(), n_clusters, trigger, sig_pin.numpy().copy(), t_start)
         self._pins.append((red_pin, sig_pin))
