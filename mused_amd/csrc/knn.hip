@@ -131,7 +131,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __r
   __shared__ int ws[SEL_WAVES];
   __shared__ unsigned long long s_red[2 * SEL_WAVES];
   __shared__ unsigned long long s_prefix, s_maskbits;
-  __shared__ int s_remaining, s_shift, s_done, s_ncand;
+  __shared__ int s_remaining, s_shift, s_done, s_ncand, s_eqcount;
   __shared__ unsigned long long cand_key[256];
   __shared__ int cand_idx[256];
 
@@ -219,44 +219,42 @@ __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __r
   unsigned long long thr;  // k-th smallest key
   int need_eq;             // how many keys == thr are selected (smallest indices first)
   if (s_done) {
-    // gather the undecided bin (<= 256 keys, ascending index order via ordered append)
+    // gather the undecided bin (<= 256 keys) with an LDS atomic append; the order does not matter,
+    // the ranking below is by (key, column)
     const unsigned long long pmask = s_maskbits, prefix = s_prefix;
-    for (int base = 0; base < n; base += SEL_THREADS) {
-      const int i = base + tid;
-      unsigned long long key = 0;
-      int f = 0;
-      if (i < n) {
-        key = key_at(i);
-        f = ((key & pmask) == prefix);
-      }
-      int tot;
-      const int pos = block_excl_scan(f, ws, tot);
-      const int off = s_ncand;
-      if (f) {
-        cand_key[off + pos] = key;
-        cand_idx[off + pos] = i;
-      }
-      __syncthreads();
-      if (tid == 0) s_ncand = off + tot;
-      __syncthreads();
-    }
-    const int nc = s_ncand, rem = s_remaining;  // the rem-th smallest (1-based) of the candidates
-    if (tid < nc) {
-      const unsigned long long mk = cand_key[tid];
-      int rank = 0;  // number of candidates strictly before me in (key, index) order
-      for (int j = 0; j < nc; ++j) {
-        const unsigned long long kj = cand_key[j];
-        rank += (kj < mk) || (kj == mk && j < tid);
-      }
-      if (rank == rem - 1) {
-        s_prefix = mk;
-        int eq_before = 0;
-        for (int j = 0; j < tid; ++j) eq_before += (cand_key[j] == mk);
-        s_remaining = eq_before + 1;
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      const unsigned long long key = key_at(i);
+      if ((key & pmask) == prefix) {
+        const int pos = atomicAdd(&s_ncand, 1);
+        cand_key[pos] = key;
+        cand_idx[pos] = i;
       }
     }
     __syncthreads();
+    const int nc = s_ncand, rem = s_remaining;  // the rem-th smallest (1-based) of the candidates
+    if (tid < nc) {
+      const unsigned long long mk = cand_key[tid];
+      const int mi = cand_idx[tid];
+      int rank = 0, eq_before = 0, eq_all = 0;
+      for (int j = 0; j < nc; ++j) {
+        const unsigned long long kj = cand_key[j];
+        const bool same = (kj == mk);
+        const bool before = same && cand_idx[j] < mi;
+        rank += (kj < mk) || before;
+        eq_before += before;
+        eq_all += same;
+      }
+      if (rank == rem - 1) {
+        s_prefix = mk;
+        s_remaining = eq_before + 1;
+        s_eqcount = eq_all;
+      }
+    }
+    __syncthreads();
+  } else if (tid == 0) {
+    s_eqcount = -1;  // unknown: the general emit path counts
   }
+  __syncthreads();
   thr = s_prefix;
   need_eq = s_remaining;
 
@@ -264,6 +262,20 @@ __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __r
   unsigned long long* mrow = out_mask ? out_mask + (long)row * mask_words : nullptr;
   // LDS bitmask staging reuses hist/cand arrays is awkward for large n; write mask words with
   // wave ballots instead: each group of 64 consecutive columns is one word owned by one wave.
+  if (!out_idx && s_eqcount == need_eq) {
+    // common case: every key equal to the threshold is selected (no tie is cut) and only the bitmask
+    // is wanted -> one ballot per 64 columns, no prefix sums, no barriers
+    for (int base = 0; base < n; base += SEL_THREADS) {
+      const int i = base + tid;
+      const bool sel = (i < n) && (key_at(i) <= thr) && (i != row);
+      const unsigned long long bal = __ballot(sel);
+      const int word = i >> 6;
+      if ((tid & 63) == 0 && word < mask_words) mrow[word] = bal;
+    }
+    const int first_free = ((n + SEL_THREADS - 1) / SEL_THREADS) * (SEL_THREADS / 64);
+    for (int w = first_free + tid; w < mask_words; w += SEL_THREADS) mrow[w] = 0ull;
+    return;
+  }
   int eq_seen = 0, emitted = 0;
   for (int base = 0; base < n; base += SEL_THREADS) {
     const int i = base + tid;
