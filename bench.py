@@ -163,9 +163,18 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): MUSED_DIST_BACKEND=gloo keeps the
+    # collectives on CPU tensors, MUSED_FORCE_DEVICE=0 puts every rank on one device
+    backend = os.environ.get("MUSED_DIST_BACKEND", "nccl")
+    if "MUSED_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["MUSED_FORCE_DEVICE"])
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from mused_amd import distributed as mdist
     from mused_amd import matrix_operations as mo
@@ -204,7 +213,7 @@ def main():
 
         # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
         R0 = float((rows_all[0, 0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
-        R = mdist.broadcast_scalar(R0, 0, device="cuda") if world > 1 else R0
+        R = mdist.broadcast_scalar(R0, 0, device=coll_dev) if world > 1 else R0
         sketch = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=B)
     # different priorities -> different HIP hardware queues (two default-priority streams can land on the
     # same queue and then run strictly in order)
@@ -268,7 +277,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -280,7 +289,7 @@ def main():
     raw_local = np.array([by_trigger[(bases[p] + t + 1) * W - 1] for p in range(B) for t in range(Wu, Wu + blks[p])],
                          dtype=np.int64)
     counts = [K] * world
-    raw_all = mdist.gather_raw_labels(raw_local, counts, device="cuda")
+    raw_all = mdist.gather_raw_labels(raw_local, counts, device=coll_dev)
     all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
 
     if rank == 0:
