@@ -147,8 +147,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
   const int z = blockIdx.z;
   const int nwg = g.tiles_m * g.tiles_n;
   const int wg = xcd_remap(blockIdx.x, nwg);
-  const int tm = wg / g.tiles_n;
-  const int tn = wg - tm * g.tiles_n;
+  // grouped tile order: consecutive workgroup ids (one XCD, dispatched together) cover 8 tile-rows x 8
+  // tile-columns, so that the ~64 tiles in flight on an XCD re-use 8 A row-panels and 8 B column-panels
+  // out of its L2 instead of streaming 64 different B panels from the Infinity Cache
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * g.tiles_n;
+  const int group_id = wg / per_group;
+  const int first_m = group_id * GROUP_M;
+  const int group_size = min(g.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (wg % group_size);
+  const int tn = (wg % per_group) / group_size;
   const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
   int k_lo = 0, k_hi = g.K;
