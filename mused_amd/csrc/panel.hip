@@ -175,10 +175,10 @@ __global__ __launch_bounds__(1024) void qr_house_kernel(double* __restrict__ Y, 
 
 // wpart[chunk][c] = sum_{i in chunk, i >= j} v_i * T[i][c]   for c in [c_lo, c_hi)
 // (v = column j of Y; T is Y itself during factorisation, the Q accumulator afterwards)
-__global__ __launch_bounds__(256) void qr_dot_kernel(const double* __restrict__ Y, long ldy, int j,
-                                                    const double* __restrict__ T, long ldt, int n, int c_lo,
-                                                    int c_hi, double* __restrict__ wpart, int wld) {
-  __shared__ double red[4][64];
+__global__ __launch_bounds__(1024) void qr_dot_kernel(const double* __restrict__ Y, long ldy, int j,
+                                                     const double* __restrict__ T, long ldt, int n, int c_lo,
+                                                     int c_hi, double* __restrict__ wpart, int wld) {
+  __shared__ double red[16][64];
   const int chunk = blockIdx.x;
   const int r0 = max(j, chunk * PANEL_ROWS_PER_WG);
   const int r1 = min(n, (chunk + 1) * PANEL_ROWS_PER_WG);
@@ -187,10 +187,15 @@ __global__ __launch_bounds__(256) void qr_dot_kernel(const double* __restrict__ 
     const int c = cb + tx;
     double s = 0.0;
     if (c < c_hi)
-      for (int i = r0 + ty; i < r1; i += 4) s += Y[(long)i * ldy + j] * T[(long)i * ldt + c];
+      for (int i = r0 + ty; i < r1; i += 16) s += Y[(long)i * ldy + j] * T[(long)i * ldt + c];
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < c_hi) wpart[(long)chunk * wld + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    if (ty == 0 && c < c_hi) {
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) acc += red[w][tx];
+      wpart[(long)chunk * wld + c] = acc;
+    }
     __syncthreads();
   }
 }
@@ -233,7 +238,7 @@ int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* 
     hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, Y, n, ldy, j, tau);
     if (j + 1 < r) {
       const int first = j / PANEL_ROWS_PER_WG;
-      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(256), 0, st, Y, ldy, j, Y, ldy, n, j + 1, r, wpart, wld);
+      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, Y, ldy, n, j + 1, r, wpart, wld);
       hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j - 1), st, Y,
                          ldy, j, Y, ldy, n, j + 1, r, wpart, wld, nchunk, first, tau);
     }
@@ -241,7 +246,7 @@ int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* 
   hipLaunchKernelGGL(set_identity_kernel, dim3(cdiv((long)n * r, 256)), dim3(256), 0, st, Q, n, r, ldq);
   for (int j = r - 1; j >= 0; --j) {
     const int first = j / PANEL_ROWS_PER_WG;
-    hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(256), 0, st, Y, ldy, j, Q, ldq, n, j, r, wpart, wld);
+    hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, Q, ldq, n, j, r, wpart, wld);
     hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j), st, Y, ldy, j,
                        Q, ldq, n, j, r, wpart, wld, nchunk, first, tau);
   }
