@@ -26,6 +26,9 @@ struct EigPlan {
   double* Gc;  // OSJ: batch x ldn x ldn, column-major working copy
   double* lam; // OSJ: batch x ldn column norms
   int* notconv;  // OSJ: sweeps x batch convergence flags
+  int wavek;     // OSJ: 1 = wave-private kernel (orders <= 256)
+  int sortcols;  // OSJ: store columns by descending norm inside each block pair
+  double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv points into)
   // live profiling (off by default): HIP events around every replay of the sweep graph
   bool prof;
   int prof_n;
@@ -319,6 +322,32 @@ __device__ __forceinline__ void osj_rotation(double pp, double qq, double pq, do
   }
 }
 
+// The same rotation without a branch and with a shorter dependency chain, returning (c, t = s / c) -- what
+// the scaled ("fast") rotations need.  With a = qq - pp, b = 2 pq:
+//     t = sign(a b) |b| / (|a| + sqrt(a^2 + b^2))          (the small root of t^2 + 2 zeta t - 1 = 0)
+// costs one rsq and one rcp; their hardware seeds are good to ~5e-8, ONE Newton step (2e-15) is enough for
+// the angle (an angle error only leaves that fraction of the inner product behind), TWO are used for
+// c = 1 / sqrt(1 + t^2), which rescales the columns and has to be exact to rounding.
+__device__ __forceinline__ void osj_rotation_t(double pp, double qq, double pq, double& c, double& t, double& npp,
+                                               double& nqq) {
+  const double a = qq - pp, b = pq + pq;
+  const double s2 = fma(a, a, b * b);
+  const bool rot = (pq * pq > 1e-30 * (pp * qq)) && (s2 > 0.0) && (s2 < 1e300);
+  double rs = __builtin_amdgcn_rsq(s2);
+  rs = rs * fma(-0.5 * s2, rs * rs, 1.5);
+  const double den = fma(s2, rs, fabs(a));
+  double rc = __builtin_amdgcn_rcp(den);
+  rc = fma(rc, fma(-den, rc, 1.0), rc);
+  double tt = fabs(b) * rc;
+  tt = ((a < 0.0) != (b < 0.0)) ? -tt : tt;
+  t = rot ? tt : 0.0;
+  const double h = fma(t, t, 1.0);  // in [1, 2]
+  const double cc = osj_rsqrt(h);
+  c = rot ? cc : 1.0;
+  npp = fma(-t, pq, pp);
+  nqq = fma(t, pq, qq);
+}
+
 // Pairing schedules of the columns held by one workgroup (compile-time: register indices are constants).
 //   CROSS = false: round robin over all C2 columns (C2 - 1 steps of C2 / 2 pairs): every pair once.
 //   CROSS = true : only pairs (i, CB + (i + step) % CB) between the two blocks (CB steps of CB pairs);
@@ -335,11 +364,19 @@ __host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
 
 template <int CB, int NT, int MODE, int DBG = 0>
 __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
-                                                      int* __restrict__ notconv, int sweep) {
+                                                      int* __restrict__ notconv, int sweep,
+                                                      const double* __restrict__ trace, int sortcols) {
   // ADAPTIVE SWEEPS: notconv[sweep * batch + matrix] is set by any workgroup that met, in this sweep, a
-  // column pair with cos^2 > 1e-16; a matrix whose previous sweep set nothing is converged (that sweep
-  // left every cosine below ~1e-16 by quadratic convergence) and its workgroups return at once.
+  // column pair with cos^2 > 1e-16 whose SMALLER column is still above 1e-13 * trace(G) (columns converge
+  // to lambda_j u_j: pairs inside the numerical null space never settle in the relative sense and carry
+  // nothing the path uses); a matrix whose previous sweep set nothing is converged (that sweep left
+  // every such cosine below ~1e-16 by quadratic convergence) and its workgroups return at once.
   if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;
+  double small2 = 0.0;
+  if (trace) {
+    const double tr = trace[blockIdx.y];
+    small2 = 1e-26 * tr * tr;
+  }
   // MODE 1: block pair (bp, bq) of the round-robin, cross pairs only; MODE 2: ONE block of 2*CB
   // consecutive columns (blockIdx.x), all pairs inside it; MODE 0: block pair, all pairs.
   // DBG != 0: timing-only ablations (results are wrong): 2 no rotation maths, 3 no barrier, 4 no apply.
@@ -427,16 +464,15 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
       }
       const double dp = dsc[wave][p], dq = dsc[wave][q];
       const double pq = raw * dp * dq;
-      active |= (pq * pq > 1e-16 * (nrm[wave][p] * nrm[wave][q]));
-      double c = 1.0, s = 0.0, npp, nqq;
+      active |= (pq * pq > 1e-16 * (nrm[wave][p] * nrm[wave][q])) && (fmin(nrm[wave][p], nrm[wave][q]) > small2);
+      double c = 1.0, tt = 0.0, npp, nqq;
       if constexpr (DBG == 2) {
-        c = 0.8; s = 0.6; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
+        c = 0.8; tt = 0.75; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
       } else {
-        osj_rotation(nrm[wave][p], nrm[wave][q], pq, c, s, npp, nqq);
+        osj_rotation_t(nrm[wave][p], nrm[wave][q], pq, c, tt, npp, nqq);
       }
       double tp = 0.0, tq = 0.0;
-      if (s != 0.0) {
-        const double tt = s * (c * (1.0 + (s * s) / (c * c)));  // t = s / c without a divide: 1/c = c (1 + t^2)
+      if (tt != 0.0) {
         const double ip = isc[wave][p], iq = isc[wave][q];
         tp = tt * dq * ip;
         tq = tt * dp * iq;
@@ -474,7 +510,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
       const double o = nrm[wave][j];
       rank += (o > mine) || (o == mine && j < lane);
     }
-    dest[wave][lane] = rank;
+    dest[wave][lane] = sortcols ? rank : lane;
   }
 #pragma unroll
   for (int j = 0; j < C2; ++j) {
@@ -486,8 +522,263 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
   (void)n;
 }
 
+// ---- wave-private variant (orders <= 256) -----------------------------------------------------------
+// Same sweep (every column pair once: pairs inside a block first, then the block-pair rounds), but the 64
+// columns of a workgroup are dealt to its 4 waves as 8 SETS of 8 columns, two sets per wave, and lane l
+// of every wave holds rows l, l + 64, ... (RP = n / 64 rows) of its 16 columns.  All 64 pairs between a
+// wave's two sets (8 steps of 8 disjoint pairs) and the pairs inside them (7 steps) are then wave-private
+// work: RP products per pair are summed in the lane, ONE 8-value transpose-reduce finishes the dot
+// products inside the wave (the row-per-thread kernel above reduces 32 values per step and needs an LDS hop
+// plus a workgroup barrier for the cross-wave sum), every lane computes the rotation of "its" pair, and
+// the waves run without any barrier until the sets are dealt again: one set per wave goes through LDS
+// (scales folded in) at each of the 3 (block-pair round) or 6 (round 0: pairs inside the two blocks
+// first) re-deals of a launch.
+//   sets 0-3 = columns of block bp, 4-7 = block bq.  Re-deal table (A = fixed slot, B = exchanged slot;
+//   "swap" exchanges a wave's slots first):
+//     round 0 :  (0,1)(2,3)(4,5)(6,7)  intra-set pairs, then A x B
+//                swap w1,w3; B: w0<->w1, w2<->w3   -> (0,2)(3,1)(4,6)(7,5)
+//                swap w1,w3; B: w0<->w1, w2<->w3   -> (0,3)(1,2)(4,7)(5,6)     all pairs inside bp, bq done
+//                B: w0<->w2, w1<->w3               -> (0,7)(1,6)(4,3)(5,2)
+//                swap w2,w3; B ring w <- w+1       -> (0,6)(1,4)(3,5)(2,7) -> (0,4)(1,5)(3,7)(2,6) -> (0,5)(1,7)(3,6)(2,4)
+//     round r :  (0,4)(1,5)(2,6)(3,7), then three times B ring w <- w+1.
+constexpr int OSJW_SC = 8;   // columns per set
+constexpr int OSJW_NW = 4;   // waves per workgroup
+
+template <int RP>
+struct OsjwShared {
+  double xfer[OSJW_NW][OSJW_SC * RP][64];  // one set per wave in flight
+  double xnrm[OSJW_NW][OSJW_SC];
+  int xid[OSJW_NW];
+  double nrm[OSJW_NW][2 * OSJW_SC];  // true squared norms of the wave's 16 columns
+  double dsc[OSJW_NW][2 * OSJW_SC];  // column scales d_j (column held as d_j * x_j)
+  double isc[OSJW_NW][2 * OSJW_SC];  // 1 / d_j
+  double2 tau[OSJW_NW][OSJW_SC];
+};
+
+// one step: 8 disjoint pairs (P(k), Q(k)) of the wave's 16 columns (compile-time indices)
+template <int RP, bool INTRA, int T>
+__device__ __forceinline__ void osjw_step(double (&x)[2 * OSJW_SC * RP], OsjwShared<RP>& sh, int wave, int lane,
+                                          double small2, int& active) {
+  constexpr int SC = OSJW_SC;
+  auto P = [](int k) constexpr { return INTRA ? (k / 4) * SC + osj_pair_p(SC, T, k % 4) : k; };
+  auto Q = [](int k) constexpr { return INTRA ? (k / 4) * SC + osj_pair_q(SC, T, k % 4) : SC + (k + T) % SC; };
+  // this lane's pair (known before the dot products: the reads of its scalars overlap them)
+  const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);  // as wave_treduce<8> deals them
+  int lp, lq;
+  int tv = T;  // opaque copy: the (lane-dependent) LDS addresses are recomputed per step (3 VALU ops) instead
+  asm volatile("" : "+s"(tv));  //   of being kept alive -- and spilled -- across the phases of a launch
+  if (INTRA) {
+    const int m = SC - 1, kk = idx & 3;
+    const int a = (kk == 0) ? m : (tv + kk) % m;
+    const int b = (kk == 0) ? (tv % m) : ((tv - kk + m) % m);
+    lp = (idx >> 2) * SC + (a < b ? a : b);
+    lq = (idx >> 2) * SC + (a < b ? b : a);
+  } else {
+    lp = idx;
+    lq = SC + ((idx + tv) & (SC - 1));
+  }
+  const double dp = sh.dsc[wave][lp], dq = sh.dsc[wave][lq];
+  const double pp = sh.nrm[wave][lp], qq = sh.nrm[wave][lq];
+  const double ip = sh.isc[wave][lp], iq = sh.isc[wave][lq];
+  double dv[SC];
+#pragma unroll
+  for (int k = 0; k < SC; ++k) {
+    const int p = P(k), q = Q(k);
+    double acc = x[p * RP] * x[q * RP];
+#pragma unroll
+    for (int i = 1; i < RP; ++i) acc = fma(x[p * RP + i], x[q * RP + i], acc);
+    dv[k] = acc;
+  }
+  int idx2;
+  const double raw = wave_treduce<SC>(dv, lane, idx2);  // every lane: the dot product of pair idx
+  {
+    const double pq = raw * dp * dq;
+    // small2 < 0: fixed sweep count, no convergence flag (kept as a branch per step: left unconditional the
+    // compiler sinks all comparisons of a launch to its end and keeps their operands alive until then)
+    if (small2 >= 0.0) active |= (pq * pq > 1e-16 * (pp * qq)) && (fmin(pp, qq) > small2);
+    double c, tt, npp, nqq;
+    osj_rotation_t(pp, qq, pq, c, tt, npp, nqq);
+    const double ic = c * fma(tt, tt, 1.0);  // 1 / c
+    if ((lane & 7) == 0) {
+      sh.nrm[wave][lp] = npp;
+      sh.nrm[wave][lq] = nqq;
+      sh.dsc[wave][lp] = dp * c;
+      sh.dsc[wave][lq] = dq * c;
+      sh.isc[wave][lp] = ip * ic;
+      sh.isc[wave][lq] = iq * ic;
+      sh.tau[wave][idx] = make_double2(tt * dq * ip, tt * dp * iq);
+    }
+  }
+  // same wave wrote tau: LDS operations of a wave complete in order
+#pragma unroll
+  for (int k = 0; k < SC; ++k) {
+    if (RP >= 4 && k == SC / 2) __builtin_amdgcn_sched_barrier(0);  // two batches of tau reads: fewer live registers
+    const double2 t2 = sh.tau[wave][k];
+    const int p = P(k), q = Q(k);
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const double xp = x[p * RP + i], xq = x[q * RP + i];
+      x[p * RP + i] = fma(-t2.x, xq, xp);
+      x[q * RP + i] = fma(t2.y, xp, xq);
+    }
+  }
+}
+
+template <int RP, bool INTRA, int T = 0>
+__device__ __forceinline__ void osjw_phase(double (&x)[2 * OSJW_SC * RP], OsjwShared<RP>& sh, int wave, int lane,
+                                           double small2, int& active) {
+  constexpr int NSTEP = INTRA ? OSJW_SC - 1 : OSJW_SC;
+  if constexpr (T < NSTEP) {
+    osjw_step<RP, INTRA, T>(x, sh, wave, lane, small2, active);
+    osjw_phase<RP, INTRA, T + 1>(x, sh, wave, lane, small2, active);
+  }
+}
+
+// re-deal: (optionally swap the wave's slots,) hand slot B to LDS and take the set wave `src` handed in
+template <int RP>
+__device__ __forceinline__ void osjw_deal(double (&x)[2 * OSJW_SC * RP], OsjwShared<RP>& sh, int wave, int lane,
+                                          bool do_swap, int src, int& ida, int& idb) {
+  constexpr int SC = OSJW_SC;
+  if (do_swap) {  // wave-uniform
+#pragma unroll
+    for (int e = 0; e < SC * RP; ++e) {
+      const double t = x[e];
+      x[e] = x[SC * RP + e];
+      x[SC * RP + e] = t;
+    }
+    if (lane < SC) {
+      const double n0 = sh.nrm[wave][lane], d0 = sh.dsc[wave][lane], i0 = sh.isc[wave][lane];
+      sh.nrm[wave][lane] = sh.nrm[wave][SC + lane];
+      sh.dsc[wave][lane] = sh.dsc[wave][SC + lane];
+      sh.isc[wave][lane] = sh.isc[wave][SC + lane];
+      sh.nrm[wave][SC + lane] = n0;
+      sh.dsc[wave][SC + lane] = d0;
+      sh.isc[wave][SC + lane] = i0;
+    }
+    const int t = ida;
+    ida = idb;
+    idb = t;
+  }
+#pragma unroll
+  for (int j = 0; j < SC; ++j) {
+    const double d = sh.dsc[wave][SC + j];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) sh.xfer[wave][j * RP + i][lane] = x[(SC + j) * RP + i] * d;
+  }
+  if (lane < SC) sh.xnrm[wave][lane] = sh.nrm[wave][SC + lane];
+  if (lane == 0) sh.xid[wave] = idb;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < SC * RP; ++e) x[SC * RP + e] = sh.xfer[src][e][lane];
+  if (lane < SC) {
+    sh.nrm[wave][SC + lane] = sh.xnrm[src][lane];
+    sh.dsc[wave][SC + lane] = 1.0;
+    sh.isc[wave][SC + lane] = 1.0;
+  }
+  idb = sh.xid[src];
+  __syncthreads();  // everyone has taken its set: the buffers may be written again
+}
+
+template <int RP, bool PREFIX>
+__global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb, int round,
+                                                           int* __restrict__ notconv, int sweep,
+                                                           const double* __restrict__ trace) {
+  if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
+  double small2 = notconv ? 0.0 : -1.0;
+  if (trace) {
+    const double tr = trace[blockIdx.y];
+    small2 = 1e-26 * tr * tr;
+  }
+  constexpr int SC = OSJW_SC, CB = OSJ_CB;
+  __shared__ OsjwShared<RP> sh;
+  double* M = Gc + (long)blockIdx.y * ldn * ldn;
+  int bp, bq;
+  {
+    const int k = blockIdx.x, m = nb - 1;
+    const int a = (k == 0) ? m : (round + k) % m;
+    const int b = (k == 0) ? (round % m) : ((round - k + m) % m);
+    bp = a < b ? a : b;
+    bq = a < b ? b : a;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ida = PREFIX ? 2 * wave : wave, idb = PREFIX ? 2 * wave + 1 : 4 + wave;
+  auto set_col = [&](int sid) { return (sid < 4 ? bp * CB + SC * sid : bq * CB + SC * (sid - 4)); };
+  double x[2 * SC * RP];
+  {
+    const int ca = set_col(ida), cb = set_col(idb);
+#pragma unroll
+    for (int j = 0; j < SC; ++j)
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        x[j * RP + i] = M[(long)(ca + j) * ldn + lane + 64 * i];
+        x[(SC + j) * RP + i] = M[(long)(cb + j) * ldn + lane + 64 * i];
+      }
+  }
+  {  // squared norms of the wave's 16 columns
+    double sq[2 * SC];
+#pragma unroll
+    for (int c = 0; c < 2 * SC; ++c) {
+      double acc = x[c * RP] * x[c * RP];
+#pragma unroll
+      for (int i = 1; i < RP; ++i) acc = fma(x[c * RP + i], x[c * RP + i], acc);
+      sq[c] = acc;
+    }
+    int idx;
+    const double t = wave_treduce<2 * SC>(sq, lane, idx);
+    if ((lane & 3) == 0) {
+      sh.nrm[wave][idx] = t;
+      sh.dsc[wave][idx] = 1.0;
+      sh.isc[wave][idx] = 1.0;
+    }
+  }
+  int active = 0;
+  if constexpr (PREFIX) {
+    osjw_phase<RP, true>(x, sh, wave, lane, small2, active);
+    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP>(x, sh, wave, lane, (wave & 1) != 0, wave ^ 1, ida, idb);
+    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP>(x, sh, wave, lane, (wave & 1) != 0, wave ^ 1, ida, idb);
+    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP>(x, sh, wave, lane, false, wave ^ 2, ida, idb);
+    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP>(x, sh, wave, lane, wave >= 2, (wave + 1) & 3, ida, idb);
+  } else {
+    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
+  }
+  osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+  osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
+  osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+  osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
+  osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
+  {
+    const int ca = set_col(ida), cb = set_col(idb);
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const double da = sh.dsc[wave][j], db = sh.dsc[wave][SC + j];
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        M[(long)(ca + j) * ldn + lane + 64 * i] = x[j * RP + i] * da;
+        M[(long)(cb + j) * ldn + lane + 64 * i] = x[(SC + j) * RP + i] * db;
+      }
+    }
+  }
+  if (notconv && __any(active) && lane == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
+}
+
+template <int RP>
+static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
+  const int nb = p->ldn / OSJ_CB;
+  hipLaunchKernelGGL((osjw_kernel<RP, true>), dim3(nb / 2, p->batch), dim3(64 * OSJW_NW), 0, st, p->Gc, p->ldn, nb, 0,
+                     p->notconv, sweep, p->trace);
+  for (int round = 1; round < nb - 1; ++round)
+    hipLaunchKernelGGL((osjw_kernel<RP, false>), dim3(nb / 2, p->batch), dim3(64 * OSJW_NW), 0, st, p->Gc, p->ldn, nb,
+                       round, p->notconv, sweep, p->trace);
+}
+
 // G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
-__global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, double* __restrict__ Gc) {
+__global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, double* __restrict__ Gc,
+                                double* __restrict__ trace) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per = (long)ldn * ldn;
   if (gid >= per * gridDim.y) return;
@@ -495,7 +786,9 @@ __global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, do
   const long e = gid;
   if (e >= per) return;
   const int c = (int)(e / ldn), r = (int)(e - (long)c * ldn);
-  Gc[b * per + e] = (c < n && r < n) ? G[(long)b * n * n + (long)c * n + r] : 0.0;
+  const double v = (c < n && r < n) ? G[(long)b * n * n + (long)c * n + r] : 0.0;
+  Gc[b * per + e] = v;
+  if (trace && c == r && v != 0.0) atomicAdd(&trace[b], fabs(v));  // order-dependent rounding: threshold use only
 }
 
 // lam[b][j] = |column j| ; one wave per column
@@ -532,14 +825,23 @@ static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   // rotate the cross pairs of (2b, 2b+1); instead launch MODE 2 with half-size blocks: CB/2 columns per
   // block -> 2*(CB/2) = CB columns per workgroup = exactly one block.
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep);
+                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols);
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, NT, 1>), dim3(nb / 2, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                       nb, round, p->notconv, sweep);
+                       nb, round, p->notconv, sweep, p->trace, p->sortcols);
 }
 
 static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
   for (int sw = 0; sw < p->sweeps; ++sw) {
+    if (p->wavek) {
+      switch (p->ldn) {
+        case 64: osjw_launch_sweep<1>(p, sw, st); break;
+        case 128: osjw_launch_sweep<2>(p, sw, st); break;
+        case 192: osjw_launch_sweep<3>(p, sw, st); break;
+        default: osjw_launch_sweep<4>(p, sw, st); break;
+      }
+      continue;
+    }
     switch (p->ldn) {
       case 64: osj_launch_sweep<64>(p, sw, st); break;
       case 128: osj_launch_sweep<128>(p, sw, st); break;
@@ -597,8 +899,16 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
     // Adaptive sweep count (off by default): the all-pairs criterion also waits for the smallest
     // eigen-directions, which the path never uses, and costs more sweeps than the fixed count that is
     // enough for the upper half of the spectrum.  MUSED_EIG_ADAPTIVE=1 turns it on.
+    const char* wk = getenv("MUSED_OSJ_WAVE");  // 0: row-per-thread kernel for every order
+    p->wavek = (p->ldn <= 256 && !(wk && wk[0] == '0')) ? 1 : 0;
+    const char* so = getenv("MUSED_OSJ_SORT");
+    p->sortcols = (so && so[0] == '0') ? 0 : 1;
     const char* ad = getenv("MUSED_EIG_ADAPTIVE");
-    if (ad && ad[0] == '1') MUSED_CHECK_HIP(hipMalloc(&p->notconv, sizeof(int) * (size_t)batch * (sweeps + 1)));
+    if (ad && ad[0] == '1') {
+      // [trace (batch doubles) | flags (batch * (sweeps + 1) ints)] in one allocation, cleared together
+      MUSED_CHECK_HIP(hipMalloc(&p->trace, sizeof(double) * (size_t)batch + sizeof(int) * (size_t)batch * (sweeps + 1)));
+      p->notconv = (int*)(p->trace + batch);
+    }
   } else {
     for (int i = 0; i < 2; ++i) {
       MUSED_CHECK_HIP(hipMalloc(&p->G[i], bytes));
@@ -636,7 +946,7 @@ void eig_plan_destroy(EigPlan* p) {
   }
   if (p->Gc) (void)hipFree(p->Gc);
   if (p->lam) (void)hipFree(p->lam);
-  if (p->notconv) (void)hipFree(p->notconv);
+  if (p->trace) (void)hipFree(p->trace);
   if (p->ev0) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
@@ -679,7 +989,8 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
     *total_ms += ms;
   }
   const int nb = p->ldn / OSJ_CB;
-  *launches = (long)p->prof_n * p->sweeps * nb;  // per sweep: 1 intra launch + (nb - 1) block-pair rounds
+  // per sweep: (nb - 1) block-pair rounds, plus one launch for the pairs inside the blocks in the row-per-thread kernel
+  *launches = (long)p->prof_n * p->sweeps * (p->wavek ? nb - 1 : nb);
   *bytes_per_launch = 16.0 * (double)p->batch * p->ldn * p->ldn;
   return MUSED_OK;
 }
@@ -687,11 +998,12 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, bool allow_graph) {
   if (p->method == 1) {
     const long per = (long)p->ldn * p->ldn;
-    hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc);
     if (p->notconv) {
-      int zrc = zero_ints(p->notconv, (long)p->batch * (p->sweeps + 1), st);
+      int zrc = zero_ints((int*)p->trace, (long)p->batch * (p->sweeps + 3), st);
       if (zrc) return zrc;
     }
+    hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc,
+                       p->trace);
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->have_graph && allow_graph) {
@@ -752,12 +1064,12 @@ int mused_debug_osj_time(const double* init, int batch, int variant, int reps, d
   auto launch = [&](int round) {
     dim3 grid(nb / 2, batch), blk(256);
     switch (variant) {
-      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
-      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
-      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
-      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
-      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0); break;
-      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0);
+      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
+      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
+      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
+      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
+      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
+      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1);
     }
   };
   MUSED_CHECK_HIP(hipEventRecord(e0, st));
