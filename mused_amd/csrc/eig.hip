@@ -27,8 +27,10 @@ struct EigPlan {
   double* lam; // OSJ: batch x ldn column norms
   int* notconv;  // OSJ: sweeps x batch convergence flags
   int wavek;     // OSJ: 1 = wave-private kernel (orders <= 256)
+  bool direct;   // OSJ: the caller fills Gc itself (n == ldn): no pack pass
   int sortcols;  // OSJ: store columns by descending norm inside each block pair
-  double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv points into)
+  double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv / work point into)
+  unsigned long long* work;  // OSJ adaptive, profiling: (matrix, sweep) pairs that did work
   // live profiling (off by default): HIP events around every replay of the sweep graph
   bool prof;
   int prof_n;
@@ -159,6 +161,18 @@ __global__ void eig_extract_kernel(const double* __restrict__ G, const double* _
 // products of each step reduced across the workgroup (in-wave transpose-reduce + one LDS hop).
 // Column norms are carried in LDS and updated from the rotation, so each step reduces CB values.
 constexpr int OSJ_CB = 32;
+// Adaptive sweeps: a sweep ends the solve if none of its rotations started from a column pair that still
+// matters.  With tr = trace(G) (>= lam_max), columns g_j = lam_j u_j, pq = g_p . g_q, a pair matters when
+//   cos^2 = pq^2 / (pp qq) > 1e-13        (what a sweep of smaller cosines leaves behind is second order), and
+//   min(pp, qq) > (1e-12 tr)^2            (columns in the numerical null space never settle relatively), and
+//   pq^2 > (1e-14 tr / n)^2 (pp + qq)     (mixing u_p, u_q by the leftover angle ~ pq / (pp - qq) moves
+//                                          sum_j f(lam_j) u_j u_j^T by ~ |pq| / (lam_p + lam_q): pairs deep in
+//                                          the small, clustered end of the spectrum converge last and move it
+//                                          by less than 1e-14 of the mean eigenvalue).
+constexpr double OSJ_CONV_COS2 = 1e-10;
+__device__ __forceinline__ bool osj_pair_active(double pq2, double pp, double qq, double floor2, double abs_ratio) {
+  return (pq2 > OSJ_CONV_COS2 * (pp * qq)) && (fmin(pp, qq) > floor2) && (pq2 > floor2 * abs_ratio * (pp + qq));
+}
 
 __host__ __device__ constexpr int osj_pair_p(int m2, int step, int k) {
   // round robin on m2 (even) players; returns the smaller index of pair k at `step`
@@ -367,15 +381,15 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
                                                       int* __restrict__ notconv, int sweep,
                                                       const double* __restrict__ trace, int sortcols) {
   // ADAPTIVE SWEEPS: notconv[sweep * batch + matrix] is set by any workgroup that met, in this sweep, a
-  // column pair with cos^2 > 1e-16 whose SMALLER column is still above 1e-13 * trace(G) (columns converge
+  // column pair that still matters (osj_pair_active) (columns converge
   // to lambda_j u_j: pairs inside the numerical null space never settle in the relative sense and carry
   // nothing the path uses); a matrix whose previous sweep set nothing is converged (that sweep left
-  // every such cosine below ~1e-16 by quadratic convergence) and its workgroups return at once.
+  // every such cosine below ~1e-13 * n by quadratic convergence) and its workgroups return at once.
   if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;
   double small2 = 0.0;
   if (trace) {
     const double tr = trace[blockIdx.y];
-    small2 = 1e-26 * tr * tr;
+    small2 = 1e-24 * tr * tr;
   }
   // MODE 1: block pair (bp, bq) of the round-robin, cross pairs only; MODE 2: ONE block of 2*CB
   // consecutive columns (blockIdx.x), all pairs inside it; MODE 0: block pair, all pairs.
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
       }
       const double dp = dsc[wave][p], dq = dsc[wave][q];
       const double pq = raw * dp * dq;
-      active |= (pq * pq > 1e-16 * (nrm[wave][p] * nrm[wave][q])) && (fmin(nrm[wave][p], nrm[wave][q]) > small2);
+      active |= osj_pair_active(pq * pq, nrm[wave][p], nrm[wave][q], small2, 1e-4 / ((double)NT * NT));
       double c = 1.0, tt = 0.0, npp, nqq;
       if constexpr (DBG == 2) {
         c = 0.8; tt = 0.75; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
@@ -595,7 +609,7 @@ __device__ __forceinline__ void osjw_step(double (&x)[2 * OSJW_SC * RP], OsjwSha
     const double pq = raw * dp * dq;
     // small2 < 0: fixed sweep count, no convergence flag (kept as a branch per step: left unconditional the
     // compiler sinks all comparisons of a launch to its end and keeps their operands alive until then)
-    if (small2 >= 0.0) active |= (pq * pq > 1e-16 * (pp * qq)) && (fmin(pp, qq) > small2);
+    if (small2 >= 0.0) active |= osj_pair_active(pq * pq, pp, qq, small2, 1e-4 / (4096.0 * RP * RP));
     double c, tt, npp, nqq;
     osj_rotation_t(pp, qq, pq, c, tt, npp, nqq);
     const double ic = c * fma(tt, tt, 1.0);  // 1 / c
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
   double small2 = notconv ? 0.0 : -1.0;
   if (trace) {
     const double tr = trace[blockIdx.y];
-    small2 = 1e-26 * tr * tr;
+    small2 = 1e-24 * tr * tr;
   }
   constexpr int SC = OSJW_SC, CB = OSJ_CB;
   __shared__ OsjwShared<RP> sh;
@@ -777,8 +791,7 @@ static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
 }
 
 // G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
-__global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, double* __restrict__ Gc,
-                                double* __restrict__ trace) {
+__global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, double* __restrict__ Gc) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per = (long)ldn * ldn;
   if (gid >= per * gridDim.y) return;
@@ -786,9 +799,29 @@ __global__ void osj_pack_kernel(const double* __restrict__ G, int n, int ldn, do
   const long e = gid;
   if (e >= per) return;
   const int c = (int)(e / ldn), r = (int)(e - (long)c * ldn);
-  const double v = (c < n && r < n) ? G[(long)b * n * n + (long)c * n + r] : 0.0;
-  Gc[b * per + e] = v;
-  if (trace && c == r && v != 0.0) atomicAdd(&trace[b], fabs(v));  // order-dependent rounding: threshold use only
+  Gc[b * per + e] = (c < n && r < n) ? G[(long)b * n * n + (long)c * n + r] : 0.0;
+}
+
+// Adaptive sweeps, start of a solve: trace[b] = sum |diag| of matrix b (scale of the convergence floor), flags
+// of all sweeps cleared.  One wave per matrix.
+__global__ void osj_begin_kernel(const double* __restrict__ Gc, int ldn, int nflag, double* __restrict__ trace,
+                                 int* __restrict__ notconv) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const double* M = Gc + (long)b * ldn * ldn;
+  double s = 0.0;
+  for (int i = lane; i < ldn; i += 64) s += fabs(M[(long)i * ldn + i]);
+  s = wave_sum(s);
+  if (lane == 0) trace[b] = s;
+  for (int f = lane; f < nflag; f += 64) notconv[(long)f * gridDim.x + b] = 0;
+}
+
+// Profiling only: adds the number of (matrix, sweep) pairs that did work in the solve just finished
+// (every matrix runs sweep 0; matrix b runs sweep s > 0 iff sweep s - 1 raised its flag).
+__global__ void osj_count_kernel(const int* __restrict__ notconv, int batch, int sweeps, unsigned long long* __restrict__ acc) {
+  int c = 0;
+  for (long i = threadIdx.x; i < (long)batch * (sweeps - 1); i += blockDim.x) c += notconv[i] != 0;
+  c = (int)wave_sum((double)c);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, (unsigned long long)(c + (threadIdx.x == 0 ? batch : 0)));
 }
 
 // lam[b][j] = |column j| ; one wave per column
@@ -902,12 +935,17 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
     const char* wk = getenv("MUSED_OSJ_WAVE");  // 0: row-per-thread kernel for every order
     p->wavek = (p->ldn <= 256 && !(wk && wk[0] == '0')) ? 1 : 0;
     const char* so = getenv("MUSED_OSJ_SORT");
-    p->sortcols = (so && so[0] == '0') ? 0 : 1;
+    p->sortcols = (so && so[0] == '0') ? 0 : 1;  // row-per-thread kernel only: helps on rank-deficient matrices
+    // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
+    // stops after the first sweep that met no column pair with cos^2 > OSJ_CONV_COS2 above the floor.  How many sweeps
+    // that takes depends on the matrix (full-rank sketch buffers ~10 at order 256, rank-deficient ones up to 16).
     const char* ad = getenv("MUSED_EIG_ADAPTIVE");
-    if (ad && ad[0] == '1') {
-      // [trace (batch doubles) | flags (batch * (sweeps + 1) ints)] in one allocation, cleared together
-      MUSED_CHECK_HIP(hipMalloc(&p->trace, sizeof(double) * (size_t)batch + sizeof(int) * (size_t)batch * (sweeps + 1)));
-      p->notconv = (int*)(p->trace + batch);
+    if (!(ad && ad[0] == '0')) {
+      // [trace (batch doubles) | work counter (1 x u64) | flags (batch * sweeps ints)]
+      MUSED_CHECK_HIP(hipMalloc(&p->trace, sizeof(double) * ((size_t)batch + 1) + sizeof(int) * (size_t)batch * sweeps));
+      p->work = (unsigned long long*)(p->trace + batch);
+      p->notconv = (int*)(p->trace + batch + 1);
+      MUSED_CHECK_HIP(hipMemset(p->work, 0, 8));
     }
   } else {
     for (int i = 0; i < 2; ++i) {
@@ -958,7 +996,6 @@ void eig_plan_destroy(EigPlan* p) {
   delete p;
 }
 
-double* eig_plan_input(EigPlan* p) { return p->G[0]; }
 
 // Live timing of the Jacobi sweeps: between enable and read every replay of the sweep graph is bracketed
 // by HIP events on the launch stream.  Read (blocking) returns the summed duration, the number of
@@ -975,7 +1012,10 @@ int eig_plan_profile(EigPlan* p, bool on) {
     }
   }
   p->prof = on;
-  if (on) p->prof_n = 0;
+  if (on) {
+    p->prof_n = 0;
+    if (p->work) MUSED_CHECK_HIP(hipMemset(p->work, 0, 8));
+  }
   return MUSED_OK;
 }
 
@@ -991,19 +1031,48 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
   const int nb = p->ldn / OSJ_CB;
   // per sweep: (nb - 1) block-pair rounds, plus one launch for the pairs inside the blocks in the row-per-thread kernel
   *launches = (long)p->prof_n * p->sweeps * (p->wavek ? nb - 1 : nb);
-  *bytes_per_launch = 16.0 * (double)p->batch * p->ldn * p->ldn;
+  // a launch reads and writes every element of every matrix that is still iterating; with the adaptive sweep
+  // count the launches of later sweeps find fewer (or no) such matrices: average over the launches timed
+  double frac = 1.0;
+  if (p->work && p->prof_n > 0) {
+    unsigned long long w = 0;
+    MUSED_CHECK_HIP(hipMemcpy(&w, p->work, 8, hipMemcpyDeviceToHost));
+    frac = (double)w / ((double)p->prof_n * p->sweeps * p->batch);
+  }
+  *bytes_per_launch = 16.0 * (double)p->batch * p->ldn * p->ldn * frac;
   return MUSED_OK;
+}
+
+// Column-form access for callers that can use the raw result of the one-sided solver: after
+// eig_plan_run_inplace(p, nullptr, nullptr, ...) column j of matrix b, cols[(b * ld + j) * ld + 0..n), is
+// lam_j u_j and lam[b * ld + j] its norm (the eigenvalue).  Returns false for the two-sided fallback.
+bool eig_plan_columns(EigPlan* p, const double** cols, const double** lam, int* ld) {
+  const char* rw = getenv("MUSED_EIG_RAW");
+  if (p->method != 1 || (rw && rw[0] == '0')) return false;
+  *cols = p->Gc;
+  *lam = p->lam;
+  *ld = p->ldn;
+  return true;
+}
+
+// Input buffer for a caller that writes the matrices itself; when the order needs no padding this is the
+// solver's working copy (no pack pass).
+double* eig_plan_input(EigPlan* p) {
+  const char* dd = getenv("MUSED_EIG_DIRECT");
+  if (p->method == 1 && p->n == p->ldn && !(dd && dd[0] == '0')) {
+    p->direct = true;
+    return p->Gc;
+  }
+  return p->G[0];
 }
 
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, bool allow_graph) {
   if (p->method == 1) {
     const long per = (long)p->ldn * p->ldn;
-    if (p->notconv) {
-      int zrc = zero_ints((int*)p->trace, (long)p->batch * (p->sweeps + 3), st);
-      if (zrc) return zrc;
-    }
-    hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc,
-                       p->trace);
+    if (!p->direct)
+      hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc);
+    if (p->notconv)
+      hipLaunchKernelGGL(osj_begin_kernel, dim3(p->batch), dim3(64), 0, st, p->Gc, p->ldn, p->sweeps, p->trace, p->notconv);
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->have_graph && allow_graph) {
@@ -1015,10 +1084,13 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     if (rec) {
       MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
       ++p->prof_n;
+      if (p->notconv)
+        hipLaunchKernelGGL(osj_count_kernel, dim3(1), dim3(256), 0, st, p->notconv, p->batch, p->sweeps, p->work);
     }
     hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam);
-    hipLaunchKernelGGL(osj_extract_kernel, dim3(cdiv((long)p->n * p->n, 256), p->batch), dim3(256), 0, st, p->Gc, p->lam,
-                       p->n, p->ldn, evals, V);
+    if (evals)
+      hipLaunchKernelGGL(osj_extract_kernel, dim3(cdiv((long)p->n * p->n, 256), p->batch), dim3(256), 0, st, p->Gc, p->lam,
+                         p->n, p->ldn, evals, V);
     MUSED_LAUNCH_CHECK();
     return MUSED_OK;
   }
@@ -1041,6 +1113,7 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
 int eig_plan_run(EigPlan* p, const double* G, double* evals, double* V, hipStream_t st) {
   const size_t bytes = sizeof(double) * (size_t)p->batch * p->n * p->n;
   MUSED_CHECK_HIP(hipMemcpyAsync(p->G[0], G, bytes, hipMemcpyDeviceToDevice, st));
+  p->direct = false;
   return eig_plan_run_inplace(p, evals, V, st, true);
 }
 

@@ -46,6 +46,9 @@ int eig_plan_run(EigPlan* p, const double* G, double* evals, double* V, hipStrea
 int eig_plan_profile(EigPlan* p, bool on);
 int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* bytes_per_launch);
 double* eig_plan_input(EigPlan* p);  // (batch x n x n) device buffer the caller may fill directly
+// Raw result of the one-sided solver (false: not available): cols[(b * ld + j) * ld + a] = lam_j u_j[a],
+// lam[b * ld + j] = eigenvalue j; valid after eig_plan_run_inplace(p, nullptr, nullptr, ...).
+bool eig_plan_columns(EigPlan* p, const double** cols, const double** lam, int* ld);
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t stream, bool allow_graph);
 
 }  // namespace mused

@@ -194,7 +194,7 @@ int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out
   Rsvd* h = new Rsvd();
   memset(h, 0, sizeof(*h));
   h->n_max = n_max; h->r_max = r_max; h->nnz_cap = nnz_cap;
-  h->sweeps = sweeps > 0 ? sweeps : 13;
+  h->sweeps = sweeps > 0 ? sweeps : 16;  // cap of the adaptive sweep count
   h->eig_n = (r_max + 1) & ~1;
   const size_t words = (n_max + 63) / 64;
   const size_t panel = sizeof(double) * (size_t)n_max * r_max;

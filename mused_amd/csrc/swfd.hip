@@ -91,8 +91,11 @@ __global__ void swfd_restart_kernel(double* __restrict__ buf, double* __restrict
 __global__ void swfd_set_now_kernel(long long* now, long long v) { *now = v; }
 
 // One workgroup per sketch: expiry, eigenvalue ordering, shrink, dump/keep plan, Wc.
+// (evals, U): eigenvalues and eigenvectors, row pitch ldu; cols != 0: U holds the solver's raw columns
+// lam_j u_j (column j contiguous) instead of the eigenvector matrix.
 __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restrict__ evals,
-                                                          const double* __restrict__ U, int n2, int ell, int cap,
+                                                          const double* __restrict__ U, int ldu, int cols, int n2,
+                                                          int ell, int cap,
                                                           int N, const long long* __restrict__ now_p,
                                                           const double* __restrict__ theta, int* __restrict__ meta,
                                                           long long* __restrict__ qt, long long* __restrict__ dropped,
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
   __shared__ double scale[512];  // sqrt(s2 / lam) of the top-l rows (0 = discarded)
   const int s = blockIdx.x, t = threadIdx.x;
   const long long now = *now_p;
-  const double* ev = evals + (long)s * n2;
-  const double* Us = U + (long)s * n2 * n2;
+  const double* ev = evals + (long)s * ldu;
+  const double* Us = U + (long)s * ldu * ldu;
   if (t < n2) lam[t] = ev[t];
   __syncthreads();
   if (t < n2) {
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
       double sc = 0.0;
       if (s2 > tol) {
         sc = sqrt(s2 / l);
+        if (cols) sc /= l;  // the raw column is lam u
         if (s2 >= th) {  // dump
           if (cnt == cap) {
             drop = q[head] > drop ? q[head] : drop;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
   for (int e = t; e < ell * n2; e += 1024) {
     const int i = e / n2, a = e - i * n2;
     const double sc = scale[i];
-    W[e] = (sc != 0.0) ? sc * Us[(long)a * n2 + order[i]] : 0.0;
+    W[e] = (sc != 0.0) ? sc * (cols ? Us[(long)order[i] * ldu + a] : Us[(long)a * ldu + order[i]]) : 0.0;
   }
 }
 
@@ -202,8 +206,12 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
   if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
                      (long)n2 * n2, n2, n2, d, S, 1.0, st)))
     return rc;
-  if ((rc = eig_plan_run_inplace(h->eig, h->evals, h->U, st, true))) return rc;
-  hipLaunchKernelGGL(swfd_decide_kernel, dim3(S), dim3(1024), 0, st, h->evals, h->U, n2, ell, h->cap, h->N,
+  const double *ecols = nullptr, *elam = nullptr;
+  int eld = 0;
+  const bool raw = eig_plan_columns(h->eig, &ecols, &elam, &eld);
+  if ((rc = eig_plan_run_inplace(h->eig, raw ? nullptr : h->evals, raw ? nullptr : h->U, st, true))) return rc;
+  hipLaunchKernelGGL(swfd_decide_kernel, dim3(S), dim3(1024), 0, st, raw ? elam : h->evals, raw ? ecols : h->U,
+                     raw ? eld : n2, raw ? 1 : 0, n2, ell, h->cap, h->N,
                      h->now_dev, h->theta, h->meta, h->qt, h->dropped, h->plan, h->keep_src, h->Wc);
   if ((rc = gemm_f64(true, false, h->Wc, n2, (long)ell * n2, h->buf, d, (long)n2 * d, h->T, d, (long)ell * d, ell, d,
                      n2, S, 1.0, st)))
@@ -291,7 +299,8 @@ __global__ void swfd_stack_kernel(const int* __restrict__ qsel_all, const double
 }
 
 __global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* __restrict__ evals_all,
-                                                                const double* __restrict__ U_all, int n4, int ell,
+                                                                const double* __restrict__ U_all, int ldu, int cols,
+                                                                int n4, int ell,
                                                                 int cap, const int* __restrict__ qsel_all,
                                                                 double* __restrict__ Wq_all,
                                                                 double* __restrict__ qinfo_all) {
@@ -299,8 +308,8 @@ __global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* _
   __shared__ int order[1024];
   __shared__ double scale[512];
   const int t = threadIdx.x, lane = blockIdx.x;
-  const double* evals = evals_all + (long)lane * n4;
-  const double* U = U_all + (long)lane * n4 * n4;
+  const double* evals = evals_all + (long)lane * ldu;
+  const double* U = U_all + (long)lane * ldu * ldu;
   const int* qsel = qsel_all + (long)lane * (4 + cap);
   double* Wq = Wq_all + (long)lane * ell * n4;
   double* qinfo = qinfo_all + (long)lane * 2;
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* _
     const double l = lam[order[t]];
     double s2 = l - delta;
     s2 = s2 > 0.0 ? s2 : 0.0;
-    scale[t] = (s2 > tol) ? sqrt(s2 / l) : 0.0;
+    scale[t] = (s2 > tol) ? (cols ? sqrt(s2 / l) / l : sqrt(s2 / l)) : 0.0;
   }
   if (t == 0) {
     qinfo[0] = (double)qsel[0];
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_query_kernel(const double* _
   for (int e = t; e < ell * n4; e += 1024) {
     const int i = e / n4, a = e - i * n4;
     const double sc = scale[i];
-    Wq[e] = (sc != 0.0) ? sc * U[(long)a * n4 + order[i]] : 0.0;
+    Wq[e] = (sc != 0.0) ? sc * (cols ? U[(long)order[i] * ldu + a] : U[(long)a * ldu + order[i]]) : 0.0;
   }
 }
 
@@ -383,8 +392,12 @@ static int swfd_query(Swfd* h, double* outB, double* outSigma, double* outInfo, 
   if ((rc = gemm_f64(true, true, h->stack, d, (long)n4 * d, h->stack, d, (long)n4 * d, eig_plan_input(h->eigq), n4,
                      (long)n4 * n4, n4, n4, d, B, 1.0, st)))
     return rc;
-  if ((rc = eig_plan_run_inplace(h->eigq, h->evals_q, h->Uq, st, true))) return rc;
-  hipLaunchKernelGGL(swfd_decide_query_kernel, dim3(B), dim3(1024), 0, st, h->evals_q, h->Uq, n4, ell, h->cap, h->qsel,
+  const double *ecols = nullptr, *elam = nullptr;
+  int eld = 0;
+  const bool raw = eig_plan_columns(h->eigq, &ecols, &elam, &eld);
+  if ((rc = eig_plan_run_inplace(h->eigq, raw ? nullptr : h->evals_q, raw ? nullptr : h->Uq, st, true))) return rc;
+  hipLaunchKernelGGL(swfd_decide_query_kernel, dim3(B), dim3(1024), 0, st, raw ? elam : h->evals_q, raw ? ecols : h->Uq,
+                     raw ? eld : n4, raw ? 1 : 0, n4, ell, h->cap, h->qsel,
                      h->Wq, h->qinfo);
   if ((rc = gemm_f64(true, false, h->Wq, n4, (long)ell * n4, h->stack, d, (long)n4 * d, h->Bout, d, (long)ell * d, ell,
                      d, n4, B, 1.0, st)))
@@ -435,7 +448,7 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   h->cap = 2 * ell;
   h->n2 = 2 * ell;
   h->n4 = 4 * ell;
-  h->sweeps = sweeps > 0 ? sweeps : (2 * ell <= 256 ? 11 : 13);
+  h->sweeps = sweeps > 0 ? sweeps : 16;  // cap of the adaptive sweep count (full-rank buffers stop after ~10)
   h->restart_mark = -1;
   const size_t S = h->S, n2 = h->n2, n4 = h->n4, cap = h->cap, dd = d, l = ell;
 #define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))

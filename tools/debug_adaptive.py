@@ -13,10 +13,14 @@ SW = int(os.environ.get('SW', '0'))
 sk = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=B, sweeps=SW)
 sk.fit_lanes(X[:, :256].contiguous())
 torch.cuda.synchronize()
+sk.profile(True)
 t0 = time.perf_counter()
 sk.fit_lanes(X[:, 256:].contiguous())
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+ms, nl, bpl = sk.profile_read()
+full = 16.0 * B * 2 * sk.L * 256 * 256
+print('eig ms total', ms, 'launches', nl, 'us/launch', 1e3 * ms / max(nl, 1), 'active fraction', bpl / full, 'GB/s', bpl / (1e-3 * ms / max(nl, 1)) / 1e9)
 Bm, sig, info = sk.get_device()
 sig = sig.cpu().numpy()
 print("sweeps", SW, "mode", os.environ.get("MUSED_EIG_ADAPTIVE", "0"), "L", sk.L, "ms/window/lane", 1e3 * dt / (B * (nwin * W - 256) / W))
