@@ -39,14 +39,14 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blob", choices=["blob", "gauss", "fd"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
-    ap.add_argument("--lanes", type=int, default=8,
+    ap.add_argument("--lanes", type=int, default=9,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
                          "launches (1 = strictly one window at a time)")
     return ap.parse_args()
@@ -187,10 +187,16 @@ def main():
     # (mused_swfd_*_lanes) on one HIP stream / host thread; adjacency + eigenstep + labels of the same
     # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
     # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
-    # lanes: at most --lanes; the count that minimises (lock-step groups) x (measured time of a group of B
-    # lanes at config 2: about 290 + 95 B ms -- latency-bound, so wide groups are cheap)
+    # lanes: at most --lanes; the count that minimises (lock-step groups) x (time of a group of B lanes).  A group
+    # is ~78 rotations x ~72 Jacobi launches, and a launch runs 8 L B workgroups (L levels, MAIN + AUX, 4 block
+    # pairs) over 512 resident slots (256 CUs x 2): its time is a step function of B -- B = 9 fills the
+    # second round that B = 5..8 leave partly empty (measured: 12 + 43 x rounds microseconds per launch).
+    w0 = synth.stream_window(args.kind, 0, W, d, args.seed)[0]  # window 0 of the stream fixes R
+    L_est = max(1, int(np.ceil(np.log2(max(float((w0.astype(np.float64) ** 2).sum(1).max()), 1.0))))) + 1
+    n_rot = -(-W // ell)
+    group_ms = lambda b: 60.0 + 10.0 * b + n_rot * 72 * (12.0 + 43.0 * (-(-8 * L_est * b // 512))) * 1e-3
     cand = range(1, max(1, min(args.lanes, K)) + 1)
-    B = min(cand, key=lambda b: (-(-K // b)) * (290.0 + 95.0 * b))
+    B = min(cand, key=lambda b: ((-(-K // b)) * group_ms(b), -b))
     blks = [K // B + (1 if p < K % B else 0) for p in range(B)]   # timed windows per lane
     blk = max(blks)
     T = Wu + blk                      # lock-step groups (a lane with fewer windows repeats its last one: padding)
@@ -217,7 +223,10 @@ def main():
         sketch = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=B)
     # different priorities -> different HIP hardware queues (two default-priority streams can land on the
     # same queue and then run strictly in order)
-    st_sketch, st_main = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)
+    # the adjacency / eigenstep stream gets the HIGH priority: a chain of ~3600 small dependent launches per window,
+    # each of which would otherwise queue behind a full wave of sketch workgroups
+    hi_main = os.environ.get('MUSED_BENCH_PRIO', 'main') == 'main'
+    st_sketch, st_main = torch.cuda.Stream(priority=0 if hi_main else -1), torch.cuda.Stream(priority=-1 if hi_main else 0)
     pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=False, async_labels=True, stream=st_main)
     torch.cuda.synchronize()
 
@@ -245,15 +254,22 @@ def main():
                 sk_events[t] = (ev, t_enq)
             if hi > lo:
                 sk_events[hi - 1][0].synchronize()
+        if os.environ.get("MUSED_BENCH_TRACE"):
+            print(f"[trace] sketch thread done {time.perf_counter() - ref['t']:.3f}s after its start", file=sys.stderr)
 
     def drive_main(lo, hi):
         # window order of the label chain: lane-major within the rank is restored after the run
         torch.cuda.set_device(local_rank)
+        tm0 = time.perf_counter()
         for t in range(lo, hi):
             for p in range(B):
                 if t < Wu + blks[p]:
                     pipe.process_window([rows_all[p, t]], labels[p][t], trigger=(bases[p] + t + 1) * W - 1)
+                    if os.environ.get("MUSED_BENCH_TRACE"):
+                        print(f"[trace] main enqueued window ({t},{p}) at {time.perf_counter() - tm0:.3f}s", file=sys.stderr)
         pipe.flush()
+        if os.environ.get("MUSED_BENCH_TRACE"):
+            print(f"[trace] main thread done {time.perf_counter() - tm0:.3f}s; label latencies {[round(x, 3) for x in pipe.latencies[-B:]]}", file=sys.stderr)
 
     def run_range(lo, hi):
         ths = [threading.Thread(target=drive_sketch, args=(lo, hi)), threading.Thread(target=drive_main, args=(lo, hi))]
