@@ -322,10 +322,10 @@ def main():
         stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all)
         stages["scores_gemm_ms_live_timed_region"] = gemm_live_ms
         # ---- rooflines (both measured live with HIP events on the launch streams over the timed region) ----
-        # (1) dominant kernel by time: osj_round_kernel, one round of the one-sided block Jacobi of the FD
-        #     rotation.  Per launch it streams every Gram matrix of the batch from memory and back
-        #     (16 n^2 B per matrix): HBM/Infinity-Cache bound load/store phases around a
-        #     latency-bound chain of 32 dependent pair-steps.
+        # (1) dominant kernel by time: osjw_kernel, one block-pair round of the one-sided Jacobi of the FD
+        #     rotation.  Per launch it streams every Gram matrix that is still iterating from memory and back
+        #     (16 n^2 B per matrix): load/store phases around a VALU-issue-bound chain of
+        #     32 (round 0: 63) dependent pair-steps.
         roof = None
         if sketch is not None:
             osj_ms, osj_launches, osj_bytes = sketch.profile_read()
@@ -334,15 +334,17 @@ def main():
                 osj_us = 1e3 * osj_ms / osj_launches
                 gbs = osj_bytes / (osj_us * 1e-6) / 1e9
                 tr = None
+                full_bytes = 16.0 * sketch.lanes * 2 * sketch.L * (2 * ell) ** 2   # every matrix read + written once
+                active_frac = osj_bytes / full_bytes    # < 1: adaptive sweep count, late launches find fewer matrices
                 try:
                     if args.workload == "c2":
                         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_osj.json")))
-                        if pm.get("lanes") == B:
-                            tr = pm["traffic_bytes_per_launch"]
+                        if pm.get("lanes") == B:   # PMC passes ran with every matrix active in every launch
+                            tr = pm["traffic_bytes_per_launch"] * active_frac
                 except Exception:
                     tr = None
                 roof = {
-                    "kernel": f"osj_round_kernel<32,256> (one-sided block Jacobi round of the FD rotation, "
+                    "kernel": f"osjw_kernel<{2 * ell // 64}> (block-pair round of the one-sided Jacobi of the FD rotation, "
                               f"{sketch.lanes * 2 * sketch.L} Gram matrices of order {2 * ell} per launch)",
                     "bound": "hbm",
                     "achieved": gbs,
@@ -353,6 +355,7 @@ def main():
                     "launch_us": osj_us,
                     "launches_timed": osj_launches,
                     "algorithmic_bytes_per_launch": osj_bytes,
+                    "matrices_active_per_launch_avg": active_frac * sketch.lanes * 2 * sketch.L,
                 }
         # (2) the contraction kernel: similarity GEMM X X^T on fp64 MFMA
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch

@@ -448,7 +448,9 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   h->cap = 2 * ell;
   h->n2 = 2 * ell;
   h->n4 = 4 * ell;
-  h->sweeps = sweeps > 0 ? sweeps : 16;  // cap of the adaptive sweep count (full-rank buffers stop after ~10)
+  // cap of the adaptive sweep count: full-rank buffers stop after 10-11 sweeps, dense rank-deficient Gram
+  // matrices (d < 2l, or linearly dependent rows) need up to 20 to push the null-space columns below the drop tolerance
+  h->sweeps = sweeps > 0 ? sweeps : 24;
   h->restart_mark = -1;
   const size_t S = h->S, n2 = h->n2, n4 = h->n4, cap = h->cap, dd = d, l = ell;
 #define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))

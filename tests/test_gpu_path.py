@@ -305,3 +305,22 @@ def test_config3_shapes_l256():
     np.testing.assert_allclose(sig.cpu().numpy(), s_ref, rtol=1e-8)
     np.testing.assert_allclose(emb.cpu().numpy(), e_ref, atol=1e-6 * np.abs(e_ref).max())
     eng.close()
+
+
+@pytest.mark.parametrize("d", [160, 96])
+def test_rank_deficient_buffers(d):
+    """Sketch buffers whose Gram matrices are dense AND rank deficient (row length d < 2l, and d < l): the
+    null-space columns of the one-sided Jacobi need about twice the sweeps of a full-rank buffer before they
+    fall below the drop tolerance -- the adaptive sweep count has to notice (a fixed count tuned on full-rank
+    buffers was 1e-5 .. 1e-2 off here)."""
+    from mused_amd import synth
+
+    N, ell = 700, 128
+    X, _ = synth.make_stream("blob", N + 300, d, 11)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    dev, ora = _swfd_pair(N, R, d, ell)
+    for lo, hi in [(0, 300), (300, 700), (700, 1000)]:
+        dev.fit(X[lo:hi])
+        ora.fit(X[lo:hi])
+        _compare(dev, ora, f"d={d} t={hi}")
+    dev.close()
