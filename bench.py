@@ -269,7 +269,8 @@ def main():
                         print(f"[trace] main enqueued window ({t},{p}) at {time.perf_counter() - tm0:.3f}s", file=sys.stderr)
         pipe.flush()
         if os.environ.get("MUSED_BENCH_TRACE"):
-            print(f"[trace] main thread done {time.perf_counter() - tm0:.3f}s; label latencies {[round(x, 3) for x in pipe.latencies[-B:]]}", file=sys.stderr)
+            print(f"[trace] main thread done {time.perf_counter() - tm0:.3f}s; label latencies {[round(x, 3) for x in pipe.latencies[-B:]]}"
+                  f" kmeans ms {[round(x) for x in pipe.host_ms['kmeans'][-B:]]} match ms {[round(x) for x in pipe.host_ms['match'][-B:]]}", file=sys.stderr)
 
     def run_range(lo, hi):
         ths = [threading.Thread(target=drive_sketch, args=(lo, hi)), threading.Thread(target=drive_main, args=(lo, hi))]

@@ -46,7 +46,13 @@ class StreamPipeline:
         self.out = []
         self.trace = []
         self.latencies = []
+        # host consumers: k-means of different windows is independent (a small pool), the Hungarian matching is a
+        # chain over windows (one worker, jobs run in submission order)
+        nk = max(1, int(os.environ.get("MUSED_LABEL_WORKERS", "3")))
+        self._kpool = ThreadPoolExecutor(max_workers=nk) if async_labels else None
         self._pool = ThreadPoolExecutor(max_workers=1) if async_labels else None
+        self._max_inflight = nk + 2
+        self.host_ms = {"kmeans": [], "match": []}
         # scikit-learn's k-means takes one OpenMP thread per visible core; on a many-core host (256 on the MI355X
         # boxes) that is ~3x slower for a (10k, 128) problem than a handful of threads
         self._omp_limit = None
@@ -110,29 +116,38 @@ class StreamPipeline:
         return emb, sigma
 
     # ---- host consumers -------------------------------------------------------------------------
-    def _labels(self, reduced_host, n_clusters, trigger, sigma_host, t_start):
+    def _cluster(self, job):
+        """Independent per window: wait for the embedding, k-means (main.py:97)."""
+        ev, red_pin, sig_pin, n_clusters, trigger, t_start = job
+        torch.cuda.set_device(self._device)
+        ev.synchronize()
+        reduced_host, sigma_host = red_pin.numpy().copy(), sig_pin.numpy().copy()
+        self._pins.append((red_pin, sig_pin))
+        t0 = time.perf_counter()
         clusters = mo.perform_clustering(reduced_host, n_clusters, self.seed)
+        self.host_ms["kmeans"].append(1e3 * (time.perf_counter() - t0))
+        return clusters, sigma_host
+
+    def _chain(self, fut, job):
+        """Sequential over windows: Hungarian matching against the previous window (main.py:105-119)."""
+        clusters, sigma_host = fut.result() if hasattr(fut, "result") else fut
+        trigger, t_start = job[4], job[5]
+        t0 = time.perf_counter()
         matched = mo.match_clusters(self.prev, clusters, method="hungarian", min_overlap=3)
         if matched is None or len(matched) == 0:  # main.py:114-116
             matched = np.full(self.W, 0)
+        self.host_ms["match"].append(1e3 * (time.perf_counter() - t0))
         self.prev = matched
         self.out.extend(matched)
         self.trace.append(dict(trigger=trigger, sigma=sigma_host, raw=np.asarray(clusters), matched=np.asarray(matched)))
         self.latencies.append(time.perf_counter() - t_start)
-
-    def _finish(self, job):
-        ev, red_pin, sig_pin, n_clusters, trigger, t_start = job
-        torch.cuda.set_device(self._device)
-        ev.synchronize()
-        self._labels(red_pin.numpy().copy(), n_clusters, trigger, sig_pin.numpy().copy(), t_start)
-        self._pins.append((red_pin, sig_pin))
 
     def _get_pins(self, reduced, sigma):
         while True:
             for i, (rp, sp) in enumerate(self._pins):
                 if rp.shape == reduced.shape and sp.shape == sigma.shape:
                     return self._pins.pop(i)
-            if len(self._pending) >= 3:  # back-pressure: reuse a buffer instead of growing the pool
+            if len(self._pending) >= self._max_inflight:  # back-pressure: reuse a buffer instead of growing the pool
                 self._pending.popleft().result()
                 continue
             return (torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True),
@@ -152,9 +167,9 @@ class StreamPipeline:
             ev.record()
         job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start)
         if self._pool is None:
-            self._finish(job)
+            self._chain(self._cluster(job), job)
         else:
-            self._pending.append(self._pool.submit(self._finish, job))
+            self._pending.append(self._pool.submit(self._chain, self._kpool.submit(self._cluster, job), job))
 
     def flush(self):
         while self._pending:
@@ -177,6 +192,7 @@ class StreamPipeline:
         self.flush()
         if self._pool is not None:
             self._pool.shutdown()
+            self._kpool.shutdown()
         for s in (self.swfd, self.fswfd):
             if s is not None:
                 s.close()
