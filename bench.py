@@ -102,6 +102,15 @@ def stage_profile(cfg, X, pipe, sketch, rows_all):
         out["swfd_query_ms_all_lanes"] = hip_event_ms(f_get, st, 1)
         out["swfd_levels"] = sketch.L
         out["swfd_lanes"] = sketch.lanes
+        # latency-oriented setting for comparison (not the throughput configuration that is timed): ONE window at a
+        # time through a single-lane sketch -- what a window costs when nothing is batched across windows
+        from mused_amd.swfd import SeqBasedSWFD
+
+        one = SeqBasedSWFD(N=W, R=sketch.R, d=d, sketch_dim=ell, lanes=1)
+        one.fit(X)
+        f_one = lambda: (one.fit(X), one.get_device())
+        out["swfd_window_ms_single_lane"] = hip_event_ms(f_one, st, 1)
+        one.close()
     return out
 
 

@@ -97,7 +97,7 @@ int mused_rsvd_status(void* handle, int* flags_out, int* stats_out, void* stream
 /* building blocks of the eigenstep, exported for unit tests */
 int mused_spmm_binary(const int* rowptr, const int* colidx, int n, const double* Q, long ldq, int r, double* Y,
                       long ldy, void* stream);
-/* ws_int: n + ceil(n/16) ints, ws_f64: r + ceil(n/16) doubles */
+/* ws_int: n + ceil(n/16) ints, ws_f64: 4 * (r + n) doubles */
 int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws_f64, void* stream);
 int mused_qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* ws_f64, void* stream);
 /* BLOCKING (creates/destroys its plan): eigen-decomposition of `batch` symmetric n x n matrices, n even */

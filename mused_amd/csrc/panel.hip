@@ -120,18 +120,180 @@ __global__ void lu_finalize_kernel(double* __restrict__ Y, int n, int k, long ld
   for (int c = s + tx; c < k; c += 16) y[c] = (c == s) ? 1.0 : 0.0;
 }
 
-int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, hipStream_t st) {
-  // workspace layout: pivstep[n] ints, then npart ints of candidate rows; prow[r] doubles, then npart doubles
+// ---- blocked variant: LU_NB columns per launch pair -------------------------------------------------
+// Same arithmetic, element by element and in the same order, as the column-at-a-time kernels above (the
+// results are bit-identical), organised so that nothing walks a strided column of the row-major panel:
+//   lu_trail_kernel  (n / 16 workgroups, rows in parallel): applies the LU_NB rank-1 updates of the finished
+//                    panel to the rest of each unpivoted row, stores the row's multipliers, and EXPORTS the next
+//                    LU_NB columns to a compact column-major buffer pc[c][row];
+//   lu_panel_kernel  (ONE workgroup, 1024 threads): reads pc (coalesced, 40 doubles per thread in registers),
+//                    eliminates its LU_NB columns with workgroup barriers only (pivot search, scaling, in-panel
+//                    updates), writes the multipliers back to pc, and finishes the LU_NB pivot rows to the right
+//                    of the panel (triangular solve) into prowN for the next lu_trail_kernel.
+// 2 launches per 4 columns instead of 8, one pass over the trailing matrix instead of 4.
+constexpr int LU_NB = 4;
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void lu_panel_kernel(const double* __restrict__ Y, int n, int r, long ld, int j0,
+                                                       int nbe, int* __restrict__ pivstep, double* __restrict__ pc,
+                                                       double* __restrict__ prowN) {
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ int s_win[LU_NB];
+  __shared__ double s_prow[LU_NB][LU_NB];  // [c][c2 >= c]: panel entries of the pivot row of panel column c
+  __shared__ double s_l[LU_NB][LU_NB];     // [s][t < s]: multipliers of pivot row s at the earlier panel columns
+  __shared__ double s_inv;
+  const int t = threadIdx.x;
+  double a[RPT][LU_NB];
+  bool act[RPT], act0[RPT];
+#pragma unroll
+  for (int ri = 0; ri < RPT; ++ri) {
+    const int row = t + 1024 * ri;
+    act[ri] = row < n && pivstep[row] == 0;
+    act0[ri] = act[ri];
+#pragma unroll
+    for (int c = 0; c < LU_NB; ++c) a[ri][c] = (act[ri] && c < nbe) ? pc[(long)c * n + row] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < LU_NB; ++c) {
+    if (c < nbe) {  // uniform
+      double best = -2.0;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int ri = 0; ri < RPT; ++ri) {
+        const double v = fabs(a[ri][c]);
+        if (act[ri] && v > best) { best = v; bi = t + 1024 * ri; }  // rows ascend with ri: first maximum = smallest row
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if ((t & 63) == 0) { s_val[t >> 6] = best; s_idx[t >> 6] = bi; }
+      __syncthreads();
+      if (t == 0) {
+        double b = s_val[0];
+        int ix = s_idx[0];
+        for (int w = 1; w < 16; ++w)
+          if (s_val[w] > b || (s_val[w] == b && s_idx[w] < ix)) { b = s_val[w]; ix = s_idx[w]; }
+        s_win[c] = ix;
+        pivstep[ix] = j0 + c + 1;
+      }
+      __syncthreads();
+      const int win = s_win[c];
+#pragma unroll
+      for (int ri = 0; ri < RPT; ++ri) {
+        if (t + 1024 * ri == win) {
+#pragma unroll
+          for (int c2 = 0; c2 < LU_NB; ++c2) {
+            if (c2 >= c) s_prow[c][c2] = a[ri][c2];
+            else s_l[c][c2] = a[ri][c2];
+          }
+          s_inv = 1.0 / a[ri][c];  // one IEEE divide by the owner of the pivot row, not 1024
+          act[ri] = false;
+        }
+      }
+      __syncthreads();
+      const double piv = s_prow[c][c];
+      const double inv = s_inv;
+#pragma unroll
+      for (int ri = 0; ri < RPT; ++ri) {
+        if (act[ri]) {
+          const double l = (piv != 0.0) ? a[ri][c] * inv : a[ri][c];
+          a[ri][c] = l;
+#pragma unroll
+          for (int c2 = c + 1; c2 < LU_NB; ++c2) a[ri][c2] -= l * s_prow[c][c2];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ri = 0; ri < RPT; ++ri) {
+    if (act0[ri]) {
+      const int row = t + 1024 * ri;
+#pragma unroll
+      for (int c = 0; c < LU_NB; ++c)
+        if (c < nbe) pc[(long)c * n + row] = a[ri][c];
+    }
+  }
+  // the finished pivot rows to the right of the panel (triangular solve with the unit-lower L11)
+  for (int cc = j0 + nbe + t; cc < r; cc += 1024) {
+    double u[LU_NB];
+#pragma unroll
+    for (int sgl = 0; sgl < LU_NB; ++sgl) {
+      if (sgl < nbe) {
+        double v = Y[(long)s_win[sgl] * ld + cc];
+#pragma unroll
+        for (int t2 = 0; t2 < sgl; ++t2) v -= s_l[sgl][t2] * u[t2];
+        u[sgl] = v;
+        prowN[(long)sgl * r + cc] = v;
+      }
+    }
+  }
+}
+
+// Finished panel (j0p, nbp; nbp = 0: none yet) -> rows: store the panel entries, apply its rank-1 updates in
+// column order to the right of it, export the next panel (j0p + nbp, nbn; nbn = 0: none left) to pc.
+__global__ __launch_bounds__(256) void lu_trail_kernel(double* __restrict__ Y, int n, int r, long ld, int j0p, int nbp,
+                                                      int nbn, const int* __restrict__ pivstep,
+                                                      double* __restrict__ pc, const double* __restrict__ prowN) {
+  const int row = blockIdx.x * LU_ROWS_PER_WG + (threadIdx.x >> 4);
+  const int tx = threadIdx.x & 15;
+  if (row >= n) return;
+  const int ps = pivstep[row];
+  double* y = Y + (long)row * ld;
+  const bool in_panel = nbp > 0 && ps > j0p && ps <= j0p + nbp;  // one of the pivot rows of the finished panel
+  if (ps != 0 && !in_panel) return;                             // pivoted earlier: final
+  double l[LU_NB];
+#pragma unroll
+  for (int sgl = 0; sgl < LU_NB; ++sgl) l[sgl] = (sgl < nbp) ? pc[(long)sgl * n + row] : 0.0;
+  if (tx < nbp) y[j0p + tx] = l[tx];
+  if (in_panel) return;  // multipliers (and U entries lu_finalize overwrites) stored; the rest of the row is not used
+  const int j0n = j0p + nbp;
+  for (int c = j0n + tx; c < r; c += 16) {
+    double v = y[c];
+#pragma unroll
+    for (int sgl = 0; sgl < LU_NB; ++sgl)
+      if (sgl < nbp) v -= l[sgl] * prowN[(long)sgl * r + c];
+    if (nbp > 0) y[c] = v;
+    if (c - j0n < nbn) pc[(long)(c - j0n) * n + row] = v;  // first round of the loop only: lanes 0 .. nbn - 1
+  }
+}
+
+// ws_f64_len: doubles available behind prow (the blocked path needs LU_NB * (r + n))
+int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, long ws_f64_len, hipStream_t st) {
+  // workspace layout, column-at-a-time path: pivstep[n] ints, then npart ints of candidate rows; prow[r] doubles,
+  // then npart doubles.  Blocked path: pivstep[n]; prowN[LU_NB][r], then pc[LU_NB][n].
   const int k = n < r ? n : r;
   const int npart = cdiv(n, LU_ROWS_PER_WG);
-  int* pidx = pivstep + n;
-  double* pval = prow + r;
   int zrc = zero_ints(pivstep, n, st);
   if (zrc) return zrc;
-  hipLaunchKernelGGL(lu_colmax_kernel, dim3(npart), dim3(256), 0, st, Y, n, ld, 0, pivstep, pval, pidx);
-  for (int j = 0; j < k; ++j) {
-    hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, Y, npart, r, ld, j, pval, pidx, pivstep, prow);
-    hipLaunchKernelGGL(lu_update_kernel, dim3(npart), dim3(256), 0, st, Y, n, r, ld, j, k, pivstep, prow, pval, pidx);
+  const char* ub = getenv("MUSED_LU_BLOCKED");
+  const bool blocked = n <= 10240 && ws_f64_len >= (long)LU_NB * ((long)r + n) && !(ub && ub[0] == '0');
+  if (blocked) {
+    double* prowN = prow;
+    double* pc = prow + (long)LU_NB * r;
+    int nbp = 0;
+    for (int j0 = 0; j0 < k; j0 += LU_NB) {
+      const int nbe = (k - j0) < LU_NB ? (k - j0) : LU_NB;
+      hipLaunchKernelGGL(lu_trail_kernel, dim3(npart), dim3(256), 0, st, Y, n, r, ld, j0 - nbp, nbp, nbe, pivstep, pc, prowN);
+      if (n <= 3072)
+        hipLaunchKernelGGL(lu_panel_kernel<3>, dim3(1), dim3(1024), 0, st, Y, n, r, ld, j0, nbe, pivstep, pc, prowN);
+      else
+        hipLaunchKernelGGL(lu_panel_kernel<10>, dim3(1), dim3(1024), 0, st, Y, n, r, ld, j0, nbe, pivstep, pc, prowN);
+      nbp = nbe;
+    }
+    const int j0l = ((k - 1) / LU_NB) * LU_NB;
+    hipLaunchKernelGGL(lu_trail_kernel, dim3(npart), dim3(256), 0, st, Y, n, r, ld, j0l, nbp, 0, pivstep, pc, prowN);
+  } else {
+    int* pidx = pivstep + n;
+    double* pval = prow + r;
+    hipLaunchKernelGGL(lu_colmax_kernel, dim3(npart), dim3(256), 0, st, Y, n, ld, 0, pivstep, pval, pidx);
+    for (int j = 0; j < k; ++j) {
+      hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(1024), 0, st, Y, npart, r, ld, j, pval, pidx, pivstep, prow);
+      hipLaunchKernelGGL(lu_update_kernel, dim3(npart), dim3(256), 0, st, Y, n, r, ld, j, k, pivstep, prow, pval, pidx);
+    }
   }
   hipLaunchKernelGGL(lu_finalize_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, Y, n, k, ld, pivstep);
   MUSED_LAUNCH_CHECK();
@@ -262,10 +424,10 @@ extern "C" {
 
 // In place: Y (n x r, ld) <- P*L of its LU factorisation with partial pivoting, first
 // min(n, r) columns (scipy.linalg.lu(Y, permute_l=True)[0]).
-// ws_int: n + ceil(n/16) ints, ws_f64: r + ceil(n/16) doubles.
+// ws_int: n + ceil(n/16) ints, ws_f64: 4 * (r + n) doubles.
 int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws_f64, void* stream) {
   MUSED_REQUIRE(Y && ws_int && ws_f64 && n > 0 && r > 0 && ld >= r, "mused_lu_permute_l: bad arguments");
-  return lu_permute_l(Y, n, r, ld, ws_int, ws_f64, (hipStream_t)stream);
+  return lu_permute_l(Y, n, r, ld, ws_int, ws_f64, 4l * ((long)r + n), (hipStream_t)stream);
 }
 
 // Q (n x r, ldq) <- economic Householder QR of Y (n x r, ldy; destroyed).  n >= r.

@@ -21,6 +21,7 @@ namespace mused {
 
 struct Rsvd {
   int n_max, r_max, eig_n, sweeps;
+  long prow_len;  // doubles behind prow (LU workspace)
   long nnz_cap;
   unsigned long long *mask, *mask_t;
   int *deg, *rowptr, *colidx, *degT, *rowptrT, *colidxT, *stats, *pivstep, *flags;
@@ -144,10 +145,10 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
   const double* Qcur = h->Q0;
   for (int it = 0; it < n_iter; ++it) {
     RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
-    RC(lu_permute_l(h->Qa, n, rc, ld, h->pivstep, h->prow, st));
+    RC(lu_permute_l(h->Qa, n, rc, ld, h->pivstep, h->prow, h->prow_len, st));
     rc = n < rc ? n : rc;
     RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qa, ld, rc, h->Qb, ld, st));
-    RC(lu_permute_l(h->Qb, n, rc, ld, h->pivstep, h->prow, st));
+    RC(lu_permute_l(h->Qb, n, rc, ld, h->pivstep, h->prow, h->prow_len, st));
     Qcur = h->Qb;
   }
   RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
@@ -208,7 +209,8 @@ int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out
   ALLOC(h->stats, 4 * 8); ALLOC(h->flags, 4 * 4); ALLOC(h->pivstep, 4 * ((size_t)n_max + cdiv(n_max, 16)));
   ALLOC(h->Q0, panel); ALLOC(h->Qa, panel); ALLOC(h->Qb, panel); ALLOC(h->Qf, panel); ALLOC(h->Bt, panel);
   ALLOC(h->Vsel, panel); ALLOC(h->embed, panel);
-  ALLOC(h->prow, 8 * ((size_t)r_max + cdiv(n_max, 16))); ALLOC(h->tau, 8 * (size_t)r_max);
+  h->prow_len = 4l * ((long)r_max + n_max);
+  ALLOC(h->prow, 8 * (size_t)h->prow_len); ALLOC(h->tau, 8 * (size_t)r_max);
   ALLOC(h->wpart, 8 * (size_t)r_max * cdiv(n_max, 512));
   ALLOC(h->gpart, 8 * (size_t)nsplit * r_max * r_max);
   ALLOC(h->evals, 8 * (size_t)h->eig_n); ALLOC(h->U, 8 * (size_t)h->eig_n * h->eig_n);

@@ -251,7 +251,7 @@ def test_lu_permute_l(L, n, r):
     ref, _ = scipy.linalg.lu(Y, permute_l=True)
     dY = dev(Y)
     wi = torch.empty(n + (n + 15) // 16, dtype=torch.int32, device="cuda")
-    wf = torch.empty(r + (n + 15) // 16, dtype=torch.float64, device="cuda")
+    wf = torch.empty(4 * (r + n), dtype=torch.float64, device="cuda")
     L.call("mused_lu_permute_l", P(dY), n, r, r, P(wi), P(wf), S())
     sync()
     k = min(n, r)
@@ -267,7 +267,7 @@ def test_lu_rank_deficient(L):
     Y[:, 7] = Y[:, 3]
     dY = dev(Y)
     wi = torch.empty(n + (n + 15) // 16, dtype=torch.int32, device="cuda")
-    wf = torch.empty(r + (n + 15) // 16, dtype=torch.float64, device="cuda")
+    wf = torch.empty(4 * (r + n), dtype=torch.float64, device="cuda")
     L.call("mused_lu_permute_l", P(dY), n, r, r, P(wi), P(wf), S())
     sync()
     out = dY.cpu().numpy()
