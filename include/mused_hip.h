@@ -99,6 +99,7 @@ int mused_spmm_binary(const int* rowptr, const int* colidx, int n, const double*
                       long ldy, void* stream);
 /* ws_int: n + ceil(n/16) ints, ws_f64: 4 * (r + n) doubles */
 int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws_f64, void* stream);
+/* ws_f64: r + ceil(n/512) * r + 2 n doubles; n >= r */
 int mused_qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* ws_f64, void* stream);
 /* BLOCKING (creates/destroys its plan): eigen-decomposition of `batch` symmetric n x n matrices, n even */
 int mused_syevj_batched(const double* G, int n, int batch, int sweeps, double* evals, double* V, void* stream);

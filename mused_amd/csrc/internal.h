@@ -22,7 +22,7 @@ int gemm_splitk_reduce(const double* partial, int nsplit, long count, double* ou
 // Y (n x r) <- P*L (first min(n,r) columns) ; pivstep: n + ceil(n/16) ints, prow: ws_f64_len doubles, at least
 // r + ceil(n/16); with 4 (r + n) the blocked path runs (n <= 10240)
 int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, long ws_f64_len, hipStream_t st);
-// Q (n x r) <- economic Householder Q of Y (destroyed); tau: r doubles, wpart: ceil(n/512)*r doubles
+// Q (n x r) <- economic Householder Q of Y (destroyed); tau: r doubles, wpart: ceil(n/512)*r + 2 n doubles
 int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart, hipStream_t st);
 // Y = A Q for binary CSR A
 int spmm_binary(const int* rowptr, const int* colidx, int n, const double* Q, long ldq, int r, double* Y, long ldy,

@@ -301,16 +301,18 @@ int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, l
 }
 
 // ---------------------------------------------------------------- QR -------------
-// Column j: Householder vector of Y[j:, j] in place (v_j = 1 implied, stored explicitly),
-// LAPACK dlarfg convention: beta = -sign(alpha) * hypot(alpha, |x|), tau = (beta - alpha)/beta,
-// v = x / (alpha - beta).  tau[j] = 0 when x == 0.
-__global__ __launch_bounds__(1024) void qr_house_kernel(double* __restrict__ Y, int n, long ld, int j,
-                                                       double* __restrict__ tau) {
+// Column j: Householder vector of Y[j:, j] (v_j = 1 implied, stored explicitly), LAPACK dlarfg convention:
+// beta = -sign(alpha) * hypot(alpha, |x|), tau = (beta - alpha)/beta, v = x / (alpha - beta); tau[j] = 0 when
+// x == 0.  The one-workgroup kernel never walks the strided column of the row-major panel: the update of
+// column j - 1 (rows in parallel) exports column j to the contiguous buffer `col`, this kernel turns it into
+// the contiguous Householder vector `vcol`, and the update of column j writes v back into Y.
+__global__ __launch_bounds__(1024) void qr_house_kernel(const double* __restrict__ col, int n, int j,
+                                                       double* __restrict__ tau, double* __restrict__ vcol) {
   __shared__ double s_sum[16];
   __shared__ double s_scale;
   double s = 0.0;
   for (int i = j + 1 + threadIdx.x; i < n; i += 1024) {
-    const double v = Y[(long)i * ld + j];
+    const double v = col[i];
     s += v * v;
   }
   s = wave_sum(s);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(1024) void qr_house_kernel(double* __restrict__ Y, 
   if (threadIdx.x == 0) {
     double xn2 = 0.0;
     for (int w = 0; w < 16; ++w) xn2 += s_sum[w];
-    const double alpha = Y[(long)j * ld + j];
+    const double alpha = col[j];
     if (xn2 == 0.0) {
       tau[j] = 0.0;
       s_scale = 0.0;
@@ -328,18 +330,25 @@ __global__ __launch_bounds__(1024) void qr_house_kernel(double* __restrict__ Y, 
       tau[j] = (beta - alpha) / beta;
       s_scale = 1.0 / (alpha - beta);
     }
-    Y[(long)j * ld + j] = 1.0;
+    vcol[j] = 1.0;
   }
   __syncthreads();
   const double sc = s_scale;
-  for (int i = j + 1 + threadIdx.x; i < n; i += 1024) Y[(long)i * ld + j] *= sc;
+  for (int i = j + 1 + threadIdx.x; i < n; i += 1024) vcol[i] = col[i] * sc;
+}
+
+// col[i] = Y[i][j]  (rows in parallel; only for the first column, later ones come out of qr_update_kernel)
+__global__ void qr_export_col_kernel(const double* __restrict__ Y, int n, long ld, int j, double* __restrict__ col) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) col[i] = Y[(long)i * ld + j];
 }
 
 // wpart[chunk][c] = sum_{i in chunk, i >= j} v_i * T[i][c]   for c in [c_lo, c_hi)
-// (v = column j of Y; T is Y itself during factorisation, the Q accumulator afterwards)
+// (v = vcol if given, else column j of Y; T is Y itself during factorisation, the Q accumulator afterwards)
 __global__ __launch_bounds__(1024) void qr_dot_kernel(const double* __restrict__ Y, long ldy, int j,
-                                                     const double* __restrict__ T, long ldt, int n, int c_lo,
-                                                     int c_hi, double* __restrict__ wpart, int wld) {
+                                                     const double* __restrict__ vcol, const double* __restrict__ T,
+                                                     long ldt, int n, int c_lo, int c_hi, double* __restrict__ wpart,
+                                                     int wld) {
   __shared__ double red[16][64];
   const int chunk = blockIdx.x;
   const int r0 = max(j, chunk * PANEL_ROWS_PER_WG);
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(1024) void qr_dot_kernel(const double* __restrict__
     const int c = cb + tx;
     double s = 0.0;
     if (c < c_hi)
-      for (int i = r0 + ty; i < r1; i += 16) s += Y[(long)i * ldy + j] * T[(long)i * ldt + c];
+      for (int i = r0 + ty; i < r1; i += 16) s += (vcol ? vcol[i] : Y[(long)i * ldy + j]) * T[(long)i * ldt + c];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < c_hi) {
@@ -362,14 +371,16 @@ __global__ __launch_bounds__(1024) void qr_dot_kernel(const double* __restrict__
   }
 }
 
-// T[i][c] -= tau_j * v_i * w[c],  w[c] = sum_chunk wpart[chunk][c]   (rows i >= j)
-__global__ __launch_bounds__(256) void qr_update_kernel(const double* __restrict__ Y, long ldy, int j,
+// T[i][c] -= tau_j * v_i * w[c],  w[c] = sum_chunk wpart[chunk][c]   (rows i >= j).
+// Factorisation phase (vcol given, T == Y): also Y[i][j] <- v_i and col[i] <- the updated T[i][j + 1].
+__global__ __launch_bounds__(256) void qr_update_kernel(double* __restrict__ Y, long ldy, int j,
+                                                       const double* __restrict__ vcol, double* __restrict__ col,
                                                        double* __restrict__ T, long ldt, int n, int c_lo, int c_hi,
                                                        const double* __restrict__ wpart, int wld, int nchunk,
                                                        int first_chunk, const double* __restrict__ tau) {
   extern __shared__ double w[];  // [c_hi - c_lo]
   const double tj = tau[j];
-  if (tj == 0.0) return;
+  if (tj == 0.0 && !vcol) return;
   for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
     double s = 0.0;
     for (int k = first_chunk; k < nchunk; ++k) s += wpart[(long)k * wld + c];
@@ -379,9 +390,17 @@ __global__ __launch_bounds__(256) void qr_update_kernel(const double* __restrict
   const int row = j + blockIdx.x * 16 + (threadIdx.x >> 4);
   const int tx = threadIdx.x & 15;
   if (row >= n) return;
-  const double v = Y[(long)row * ldy + j];
+  const double v = vcol ? vcol[row] : Y[(long)row * ldy + j];
   double* t = T + (long)row * ldt;
-  for (int c = c_lo + tx; c < c_hi; c += 16) t[c] -= v * w[c - c_lo];
+  if (vcol && tx == 15) Y[(long)row * ldy + j] = v;
+  for (int c = c_lo + tx; c < c_hi; c += 16) {
+    double x = t[c];
+    if (tj != 0.0) {
+      x -= v * w[c - c_lo];
+      t[c] = x;
+    }
+    if (col && c == j + 1) col[row] = x;
+  }
 }
 
 __global__ void set_identity_kernel(double* __restrict__ Q, int n, int r, long ld) {
@@ -393,24 +412,28 @@ __global__ void set_identity_kernel(double* __restrict__ Q, int n, int r, long l
 
 int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart,
                 hipStream_t st) {
-  // requires n >= r
+  // requires n >= r.  wpart: ceil(n/512) * r partial sums, then col[n], then vcol[n]
   const int nchunk = cdiv(n, PANEL_ROWS_PER_WG);
   const int wld = r;
+  double* col = wpart + (long)nchunk * r;
+  double* vcol = col + n;
+  hipLaunchKernelGGL(qr_export_col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, Y, n, ldy, 0, col);
   for (int j = 0; j < r; ++j) {
-    hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, Y, n, ldy, j, tau);
-    if (j + 1 < r) {
-      const int first = j / PANEL_ROWS_PER_WG;
-      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, Y, ldy, n, j + 1, r, wpart, wld);
-      hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j - 1), st, Y,
-                         ldy, j, Y, ldy, n, j + 1, r, wpart, wld, nchunk, first, tau);
-    }
+    hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, col, n, j, tau, vcol);
+    const int first = j / PANEL_ROWS_PER_WG;
+    if (j + 1 < r)
+      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, vcol, Y, ldy, n, j + 1, r, wpart, wld);
+    // (the last column has nothing to update: c_lo = c_hi = r; the launch only writes v back into Y)
+    hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j), st, Y, ldy, j, vcol,
+                       col, Y, ldy, n, j + 1, r, wpart, wld, nchunk, first, tau);
   }
   hipLaunchKernelGGL(set_identity_kernel, dim3(cdiv((long)n * r, 256)), dim3(256), 0, st, Q, n, r, ldq);
   for (int j = r - 1; j >= 0; --j) {
     const int first = j / PANEL_ROWS_PER_WG;
-    hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, Q, ldq, n, j, r, wpart, wld);
+    hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, (const double*)nullptr, Q, ldq, n, j,
+                       r, wpart, wld);
     hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j), st, Y, ldy, j,
-                       Q, ldq, n, j, r, wpart, wld, nchunk, first, tau);
+                       (const double*)nullptr, (double*)nullptr, Q, ldq, n, j, r, wpart, wld, nchunk, first, tau);
   }
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
@@ -431,7 +454,7 @@ int mused_lu_permute_l(double* Y, int n, int r, long ld, int* ws_int, double* ws
 }
 
 // Q (n x r, ldq) <- economic Householder QR of Y (n x r, ldy; destroyed).  n >= r.
-// ws_f64: r + ceil(n/512)*r doubles.
+// ws_f64: r + ceil(n/512)*r + 2 n doubles.
 int mused_qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* ws_f64, void* stream) {
   MUSED_REQUIRE(Y && Q && ws_f64 && n >= r && r > 0 && ldy >= r && ldq >= r, "mused_qr_economic: need n >= r");
   return qr_economic(Y, n, r, ldy, Q, ldq, ws_f64, ws_f64 + r, (hipStream_t)stream);

@@ -211,7 +211,7 @@ int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out
   ALLOC(h->Vsel, panel); ALLOC(h->embed, panel);
   h->prow_len = 4l * ((long)r_max + n_max);
   ALLOC(h->prow, 8 * (size_t)h->prow_len); ALLOC(h->tau, 8 * (size_t)r_max);
-  ALLOC(h->wpart, 8 * (size_t)r_max * cdiv(n_max, 512));
+  ALLOC(h->wpart, 8 * ((size_t)r_max * cdiv(n_max, 512) + 2 * (size_t)n_max));
   ALLOC(h->gpart, 8 * (size_t)nsplit * r_max * r_max);
   ALLOC(h->evals, 8 * (size_t)h->eig_n); ALLOC(h->U, 8 * (size_t)h->eig_n * h->eig_n);
   ALLOC(h->Cm, 8 * (size_t)r_max * r_max); ALLOC(h->sigma, 8 * (size_t)r_max); ALLOC(h->signs, 8 * (size_t)r_max);

@@ -284,7 +284,7 @@ def test_qr_economic(L, n, r):
     ref, _ = scipy.linalg.qr(Y, mode="economic")
     dY = dev(Y)
     Q = torch.empty((n, r), dtype=torch.float64, device="cuda")
-    ws = torch.empty(r + ((n + 511) // 512) * r, dtype=torch.float64, device="cuda")
+    ws = torch.empty(r + ((n + 511) // 512) * r + 2 * n, dtype=torch.float64, device="cuda")
     L.call("mused_qr_economic", P(dY), n, r, r, P(Q), r, P(ws), S())
     sync()
     q = Q.cpu().numpy()
