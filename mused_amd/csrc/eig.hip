@@ -29,6 +29,7 @@ struct EigPlan {
   int wavek;     // OSJ: 1 = wave-private kernel (orders <= 256)
   bool direct;   // OSJ: the caller fills Gc itself (n == ldn): no pack pass
   int sortcols;  // OSJ: store columns by descending norm inside each block pair
+  int sort_from; // OSJ wave kernel: first sweep that sorts
   double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv / work point into)
   unsigned long long* work;  // OSJ adaptive, profiling: (matrix, sweep) pairs that did work
   // live profiling (off by default): HIP events around every replay of the sweep graph
@@ -163,11 +164,13 @@ __global__ void eig_extract_kernel(const double* __restrict__ G, const double* _
 constexpr int OSJ_CB = 32;
 // Adaptive sweeps: a sweep ends the solve if none of its rotations started from a column pair that still
 // matters.  With tr = trace(G) (>= lam_max), columns g_j = lam_j u_j, pq = g_p . g_q, a pair matters when
-//   cos^2 = pq^2 / (pp qq) > 1e-10        (what a sweep of smaller cosines leaves behind is second order), and
+//   cos^2 = pq^2 / (pp qq) > 1e-14        (what a sweep of smaller cosines leaves behind is second order --
+//                                          except inside an exactly multiple eigenvalue, where ~1e-2 of that cosine
+//                                          can survive between the vectors of the cluster), and
 //   min(pp, qq) > (1e-12 tr)^2            (columns in the numerical null space never settle relatively).
 // (A third, absolute test -- |pq| against (lam_p + lam_q) * mean eigenvalue -- never changed a decision on the
 // matrices of this path and was dropped.)
-constexpr double OSJ_CONV_COS2 = 1e-10;
+constexpr double OSJ_CONV_COS2 = 1e-14;
 __device__ __forceinline__ bool osj_pair_active(double pq2, double pp, double qq, double floor2, double abs_ratio) {
   (void)abs_ratio;
   return (pq2 > OSJ_CONV_COS2 * (pp * qq)) & (pp > floor2) & (qq > floor2);
@@ -696,7 +699,7 @@ __device__ __forceinline__ void osjw_deal(double (&x)[2 * OSJW_SC * RP], OsjwSha
 template <int RP, bool PREFIX>
 __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb, int round,
                                                            int* __restrict__ notconv, int sweep,
-                                                           const double* __restrict__ trace) {
+                                                           const double* __restrict__ trace, int sortcols) {
   if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
   double small2 = notconv ? 0.0 : -1.0;
   if (trace) {
@@ -765,7 +768,26 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
   osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
   osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
   osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-  {
+  if (sortcols && lane == 0) sh.xid[wave] = (ida << 8) | idb;  // (xid is free after the last re-deal)
+  if (sortcols) {
+    // de Rijk at block-pair level: the 64 columns go back in descending norm (ties: current position).  Costs
+    // about one sweep on well-separated spectra and is what makes clustered / multiple eigenvalues converge.
+    __syncthreads();  // all waves' norms are final
+    // lane l stands for column (wave l / 16, slot l % 16) of the workgroup: one ballot per own column gives its rank
+    const int ow = lane >> 4, oc = lane & 15;
+    const double other = sh.nrm[ow][oc];
+    const int oid = ((oc < SC) ? (sh.xid[ow] >> 8) : (sh.xid[ow] & 255)) * SC + (oc & (SC - 1));
+#pragma unroll
+    for (int c = 0; c < 2 * SC; ++c) {
+      const double mine = sh.nrm[wave][c];
+      const int myid = (c < SC ? ida : idb) * SC + (c & (SC - 1));
+      const int pos = __popcll(__ballot((other > mine) || (other == mine && oid < myid)));
+      const int colg = (pos < CB) ? (bp * CB + pos) : (bq * CB + pos - CB);
+      const double dd = sh.dsc[wave][c];
+#pragma unroll
+      for (int i = 0; i < RP; ++i) M[(long)colg * ldn + lane + 64 * i] = x[c * RP + i] * dd;
+    }
+  } else {
     const int ca = set_col(ida), cb = set_col(idb);
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
@@ -783,11 +805,12 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
 template <int RP>
 static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB;
+  const int so = sweep >= p->sort_from ? 1 : 0;
   hipLaunchKernelGGL((osjw_kernel<RP, true>), dim3(nb / 2, p->batch), dim3(64 * OSJW_NW), 0, st, p->Gc, p->ldn, nb, 0,
-                     p->notconv, sweep, p->trace);
+                     p->notconv, sweep, p->trace, so);
   for (int round = 1; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, false>), dim3(nb / 2, p->batch), dim3(64 * OSJW_NW), 0, st, p->Gc, p->ldn, nb,
-                       round, p->notconv, sweep, p->trace);
+                       round, p->notconv, sweep, p->trace, so);
 }
 
 // G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
@@ -932,6 +955,8 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
     // Adaptive sweep count (off by default): the all-pairs criterion also waits for the smallest
     // eigen-directions, which the path never uses, and costs more sweeps than the fixed count that is
     // enough for the upper half of the spectrum.  MUSED_EIG_ADAPTIVE=1 turns it on.
+    const char* sf = getenv("MUSED_OSJ_SORT_FROM");
+    p->sort_from = sf ? atoi(sf) : 0;
     const char* wk = getenv("MUSED_OSJ_WAVE");  // 0: row-per-thread kernel for every order
     p->wavek = (p->ldn <= 256 && !(wk && wk[0] == '0')) ? 1 : 0;
     const char* so = getenv("MUSED_OSJ_SORT");

@@ -325,6 +325,39 @@ def test_syevj(L, n, batch, sweeps):
         assert not V[b][:, ~nz].any() or np.abs(ev[b][~nz]).max() <= 1e-9 * scale
 
 
+@pytest.mark.parametrize("n", [64, 192, 256, 512])
+def test_syevj_special_matrices(L, n):
+    """Degenerate inputs of the adaptive one-sided solver: zero matrix, diagonal, rank one, a multiple
+    eigenvalue, heavy rank deficiency (rank n/3, dense) -- eigenvalues to 1e-12 of the largest one within the
+    sweep cap, no NaN."""
+    rng = np.random.default_rng(n)
+    mats = [np.zeros((n, n)), np.diag(np.linspace(5.0, 0.0, n))]
+    u = rng.standard_normal(n)
+    mats.append(np.outer(u, u))
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([np.full(n // 4, 7.0), np.full(n // 4, 2.0), np.linspace(1.0, 0.5, n - 2 * (n // 4))])
+    mats.append((Qm * lam) @ Qm.T)
+    B = rng.standard_normal((n, n // 3))
+    mats.append(B @ B.T)
+    G = np.stack([0.5 * (m + m.T) for m in mats])
+    ev = torch.empty((len(mats), n), dtype=torch.float64, device="cuda")
+    V = torch.empty((len(mats), n, n), dtype=torch.float64, device="cuda")
+    dG = dev(G)
+    L.call("mused_syevj_batched", P(dG), n, len(mats), 30, P(ev), P(V), S())
+    sync()
+    ev, V = ev.cpu().numpy(), V.cpu().numpy()
+    assert np.isfinite(ev).all() and np.isfinite(V).all()
+    for b in range(len(mats)):
+        scale = max(np.abs(G[b]).max(), 1e-300)
+        ref = np.maximum(np.linalg.eigvalsh(G[b]), 0)
+        np.testing.assert_allclose(np.sort(ev[b]), ref, rtol=0, atol=1e-10 * scale, err_msg=f"matrix {b}")
+        nz = ev[b] > 1e-9 * scale  # columns of the numerical null space carry no direction (documented)
+        # inside an exactly multiple eigenvalue the adaptive stop leaves up to ~1e-9 between the vectors of the cluster
+        np.testing.assert_allclose(G[b] @ V[b][:, nz], V[b][:, nz] * ev[b][nz][None, :], atol=1e-8 * scale, err_msg=f"matrix {b}")
+        Vn = V[b][:, nz]
+        np.testing.assert_allclose(Vn.T @ Vn, np.eye(int(nz.sum())), atol=1e-8, err_msg=f"matrix {b}")
+
+
 @pytest.mark.parametrize("ell,d", [(8, 40), (16, 100), (128, 1024)])
 def test_fd_rotate(L, ell, d):
     rng = np.random.default_rng(ell + d)
