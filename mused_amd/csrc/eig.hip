@@ -165,11 +165,11 @@ constexpr int OSJ_CB = 32;
 // Adaptive sweeps: a sweep ends the solve if none of its rotations started from a column pair that still
 // matters.  With tr = trace(G) (>= lam_max), columns g_j = lam_j u_j, pq = g_p . g_q, a pair matters when
 //   cos^2 = pq^2 / (pp qq) > 1e-14        (what a sweep of smaller cosines leaves behind is second order --
-//                                          except inside an exactly multiple eigenvalue, where ~1e-2 of that cosine
-//                                          can survive between the vectors of the cluster), and
+//                                          except inside an exactly multiple eigenvalue, where ~1e-2 of that
+//                                          cosine can survive between the vectors of the cluster: 1e-9), and
 //   min(pp, qq) > (1e-12 tr)^2            (columns in the numerical null space never settle relatively).
-// (A third, absolute test -- |pq| against (lam_p + lam_q) * mean eigenvalue -- never changed a decision on the
-// matrices of this path and was dropped.)
+// Tried and dropped: an absolute test (|pq| against (lam_p + lam_q) * mean eigenvalue) and a tighter threshold
+// for pairs with |qq - pp| < 4 |pq| -- neither changed a decision on the matrices of this path.
 constexpr double OSJ_CONV_COS2 = 1e-14;
 __device__ __forceinline__ bool osj_pair_active(double pq2, double pp, double qq, double floor2, double abs_ratio) {
   (void)abs_ratio;
