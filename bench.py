@@ -102,7 +102,9 @@ def stage_profile(cfg, X, pipe, sketch, rows_all):
         out["swfd_query_ms_all_lanes"] = hip_event_ms(f_get, st, 1)
         out["swfd_levels"] = sketch.L
         out["swfd_lanes"] = sketch.lanes
-        # latency-oriented setting for comparison (not the throughput configuration that is timed): ONE window at a
+    if sketch is not None and os.environ.get("MUSED_BENCH_LATENCY_PROBE"):
+        # latency-oriented setting for comparison (not the throughput configuration that is timed; off by default so
+        # that a rocprofv3 --stats run of this script averages the same launches as the live timing): ONE window at a
         # time through a single-lane sketch -- what a window costs when nothing is batched across windows
         from mused_amd.swfd import SeqBasedSWFD
 
@@ -116,13 +118,20 @@ def stage_profile(cfg, X, pipe, sketch, rows_all):
 
 def cpu_baseline(cfg, kind, seed, with_swfd=True):
     """The CPU oracle (oracle/*.py, a port of the reference path pinned to its golden vectors) timed
-    on this box's host cores over a bounded sample of the same workload."""
-    import multiprocessing
-
+    on this box's host cores over a bounded sample of the same workload.  BLAS / OpenMP pools are capped at
+    16 threads (a one-GPU share of the host): left at one thread per visible core (256 here) the same sample
+    runs ~10x slower, which would flatter the GPU."""
     from mused_amd import synth
     from oracle import mo_oracle as omo
     from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
 
+    threads = max(1, min(16, os.cpu_count() or 1))
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter, threads = None, os.cpu_count() or 1
     W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
     X, labels = synth.stream_window(kind, 0, W, d, seed)
     t0 = time.perf_counter()
@@ -145,15 +154,18 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
         sk.fit(X64[:swfd_rows])
         sk.get()
         t_swfd_per_row = (time.perf_counter() - ts) / swfd_rows
+    if limiter is not None:
+        limiter.restore_original_limits()
     window_s = (t3 - t0) + t_swfd_per_row * W
     return {
         "value": W / window_s,
         "unit": "rows/s",
-        "cores": multiprocessing.cpu_count(),
+        "cores": threads,
         "kind": "port",
         "sample": f"1 window of {W} rows through oracle adjacency+fuse ({t1 - t0:.2f}s), eigenstep ({t2 - t1:.2f}s), "
                   f"k-means ({t3 - t2:.2f}s); SWFD oracle timed on {swfd_rows} rows "
-                  f"({t_swfd_per_row * 1e3:.2f} ms/row) and extrapolated to the window; default BLAS threading",
+                  f"({t_swfd_per_row * 1e3:.2f} ms/row) and extrapolated to the window; BLAS/OpenMP pools capped at "
+                  f"{threads} threads",
         "window_seconds": window_s,
     }
 

@@ -164,16 +164,16 @@ __global__ void eig_extract_kernel(const double* __restrict__ G, const double* _
 constexpr int OSJ_CB = 32;
 // Adaptive sweeps: a sweep ends the solve if none of its rotations started from a column pair that still
 // matters.  With tr = trace(G) (>= lam_max), columns g_j = lam_j u_j, pq = g_p . g_q, a pair matters when
-//   cos^2 = pq^2 / (pp qq) > 1e-14        (what a sweep of smaller cosines leaves behind is second order --
-//                                          except inside an exactly multiple eigenvalue, where ~1e-2 of that
-//                                          cosine can survive between the vectors of the cluster: 1e-9), and
+//   cos^2 = pq^2 / (pp qq) > cos2         (what a sweep of smaller cosines leaves behind is second order), and
 //   min(pp, qq) > (1e-12 tr)^2            (columns in the numerical null space never settle relatively).
+// cos2 = 1e-10 in the wave-private kernel: with its block-pair sort, eigenvectors come out orthogonal to 2e-10
+// even inside exactly multiple eigenvalues (tests: test_syevj_special_matrices).  The row-per-thread kernel
+// leaves ~1e-2 of the last cosine inside such a cluster and uses 1e-14 (1e-9).
 // Tried and dropped: an absolute test (|pq| against (lam_p + lam_q) * mean eigenvalue) and a tighter threshold
 // for pairs with |qq - pp| < 4 |pq| -- neither changed a decision on the matrices of this path.
-constexpr double OSJ_CONV_COS2 = 1e-14;
-__device__ __forceinline__ bool osj_pair_active(double pq2, double pp, double qq, double floor2, double abs_ratio) {
-  (void)abs_ratio;
-  return (pq2 > OSJ_CONV_COS2 * (pp * qq)) & (pp > floor2) & (qq > floor2);
+constexpr double OSJ_CONV_COS2_WAVE = 1e-10, OSJ_CONV_COS2_ROW = 1e-14;
+__device__ __forceinline__ bool osj_pair_active(double pq2, double pp, double qq, double floor2, double cos2) {
+  return (pq2 > cos2 * (pp * qq)) & (pp > floor2) & (qq > floor2);
 }
 
 __host__ __device__ constexpr int osj_pair_p(int m2, int step, int k) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
       }
       const double dp = dsc[wave][p], dq = dsc[wave][q];
       const double pq = raw * dp * dq;
-      active |= osj_pair_active(pq * pq, nrm[wave][p], nrm[wave][q], small2, 1e-4 / ((double)NT * NT));
+      active |= osj_pair_active(pq * pq, nrm[wave][p], nrm[wave][q], small2, OSJ_CONV_COS2_ROW);
       double c = 1.0, tt = 0.0, npp, nqq;
       if constexpr (DBG == 2) {
         c = 0.8; tt = 0.75; npp = nrm[wave][p] + pq; nqq = nrm[wave][q];
@@ -612,7 +612,7 @@ __device__ __forceinline__ void osjw_step(double (&x)[2 * OSJW_SC * RP], OsjwSha
     const double pq = raw * dp * dq;
     // small2 < 0: fixed sweep count, no convergence flag (kept as a branch per step: left unconditional the
     // compiler sinks all comparisons of a launch to its end and keeps their operands alive until then)
-    if (small2 >= 0.0) active |= osj_pair_active(pq * pq, pp, qq, small2, 1e-4 / (4096.0 * RP * RP));
+    if (small2 >= 0.0) active |= osj_pair_active(pq * pq, pp, qq, small2, OSJ_CONV_COS2_WAVE);
     double c, tt, npp, nqq;
     osj_rotation_t(pp, qq, pq, c, tt, npp, nqq);
     const double ic = c * fma(tt, tt, 1.0);  // 1 / c
@@ -962,7 +962,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
     const char* so = getenv("MUSED_OSJ_SORT");
     p->sortcols = (so && so[0] == '0') ? 0 : 1;  // row-per-thread kernel only: helps on rank-deficient matrices
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
-    // stops after the first sweep that met no column pair with cos^2 > OSJ_CONV_COS2 above the floor.  How many sweeps
+    // stops after the first sweep that met no column pair with cos^2 above the threshold (osj_pair_active).  How many sweeps
     // that takes depends on the matrix (full-rank sketch buffers ~10 at order 256, rank-deficient ones up to 16).
     const char* ad = getenv("MUSED_EIG_ADAPTIVE");
     if (!(ad && ad[0] == '0')) {
