@@ -10,7 +10,13 @@ One STEP = one window of W rows, already resident in HBM, through the whole path
     k-means + Hungarian matching on the host (sklearn / SciPy)  [a10]  -> event labels
 `value` = rows of all ranks / wall time of the K timed steps (max over ranks), inputs resident.
 
-    python bench.py                       # 1 GPU, K = 5, W = 1
+In-GPU concurrency (one rank): the K windows are dealt to B "lanes" (contiguous blocks of the stream, each preceded by
+its warm-up = halo window); the sketches of the lanes advance in lockstep inside shared launches, in TWO groups of
+lanes on two HIP streams, while a third, high-priority stream runs adjacency -> eigenstep of the same windows and a
+pool of host workers the k-means / matching.  `roofline` is the Jacobi round kernel as it runs in the timed region (per
+launch, next to the other group's launches), `roofline_isolated` the same kernel with the GPU to itself.
+
+    python bench.py                       # 1 GPU, K = 9, W = 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -49,6 +55,11 @@ def parse():
     ap.add_argument("--lanes", type=int, default=9,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
                          "launches (1 = strictly one window at a time)")
+    ap.add_argument("--sketch-groups", type=int, default=0,
+                    help="independent groups of lanes, each on its own HIP stream / host thread (0 = auto: 2 groups "
+                         "from 4 lanes): their launches interleave on the GPU, so the Gram / rotate GEMMs of one group "
+                         "overlap the Jacobi rounds of the other and partly filled workgroup rounds are shared.  More "
+                         "than 2 groups + the main stream exceed the hardware queues HIP hands out and serialise.")
     return ap.parse_args()
 
 
@@ -97,11 +108,11 @@ def stage_profile(cfg, X, pipe, sketch, rows_all):
     out["rsvd_ms"] = hip_event_ms(f_rsvd, st, 2)
     if sketch is not None:
         f_app = lambda: sketch.fit_lanes(rows_all[:, -1])
-        out["swfd_append_ms_all_lanes"] = hip_event_ms(f_app, st, 1)
+        out["swfd_append_ms_group0_alone"] = hip_event_ms(f_app, st, 1)
         f_get = lambda: sketch.get_device()
-        out["swfd_query_ms_all_lanes"] = hip_event_ms(f_get, st, 1)
+        out["swfd_query_ms_group0_alone"] = hip_event_ms(f_get, st, 1)
         out["swfd_levels"] = sketch.L
-        out["swfd_lanes"] = sketch.lanes
+        out["swfd_lanes_group0"] = sketch.lanes
     if sketch is not None and os.environ.get("MUSED_BENCH_LATENCY_PROBE"):
         # latency-oriented setting for comparison (not the throughput configuration that is timed; off by default so
         # that a rocprofv3 --stats run of this script averages the same launches as the live timing): ONE window at a
@@ -208,16 +219,10 @@ def main():
     # (mused_swfd_*_lanes) on one HIP stream / host thread; adjacency + eigenstep + labels of the same
     # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
     # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
-    # lanes: at most --lanes; the count that minimises (lock-step groups) x (time of a group of B lanes).  A group
-    # is ~78 rotations x ~72 Jacobi launches, and a launch runs 8 L B workgroups (L levels, MAIN + AUX, 4 block
-    # pairs) over 512 resident slots (256 CUs x 2): its time is a step function of B -- B = 9 fills the
-    # second round that B = 5..8 leave partly empty (measured: 12 + 43 x rounds microseconds per launch).
-    w0 = synth.stream_window(args.kind, 0, W, d, args.seed)[0]  # window 0 of the stream fixes R
-    L_est = max(1, int(np.ceil(np.log2(max(float((w0.astype(np.float64) ** 2).sum(1).max()), 1.0))))) + 1
-    n_rot = -(-W // ell)
-    group_ms = lambda b: 60.0 + 10.0 * b + n_rot * 72 * (12.0 + 43.0 * (-(-8 * L_est * b // 512))) * 1e-3
+    # lanes: at most --lanes; the count that minimises (lock-step steps) x (time of a step of B lanes: measured about
+    # 60 + 74 B ms at config 2 with two sketch groups, i.e. per-lane cost falls with B and 9 lanes fill the GPU).
     cand = range(1, max(1, min(args.lanes, K)) + 1)
-    B = min(cand, key=lambda b: ((-(-K // b)) * group_ms(b), -b))
+    B = min(cand, key=lambda b: ((-(-K // b)) * (60.0 + 74.0 * b), -b))
     blks = [K // B + (1 if p < K % B else 0) for p in range(B)]   # timed windows per lane
     blk = max(blks)
     T = Wu + blk                      # lock-step groups (a lane with fewer windows repeats its last one: padding)
@@ -234,49 +239,57 @@ def main():
             rows_all[p, t].copy_(torch.from_numpy(host[p][min(t, Wu + blks[p] - 1)][0]))
     labels = [[l for _, l in hp] for hp in host]
 
-    sketch = None
+    sketches, grp = [], []   # one sketch object per group of lanes; grp[g] = (first lane, one past the last lane)
     if not args.no_swfd:
         from mused_amd.swfd import SeqBasedSWFD
 
         # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
         R0 = float((rows_all[0, 0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
         R = mdist.broadcast_scalar(R0, 0, device=coll_dev) if world > 1 else R0
-        sketch = SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=B)
+        G = args.sketch_groups if args.sketch_groups > 0 else (2 if B >= 4 else 1)
+        G = max(1, min(G, B))
+        l0 = 0
+        for g in range(G):
+            l1 = l0 + B // G + (1 if g < B % G else 0)
+            grp.append((l0, l1))
+            sketches.append(SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=l1 - l0))
+            l0 = l1
+    sketch = sketches[0] if sketches else None
     # different priorities -> different HIP hardware queues (two default-priority streams can land on the
     # same queue and then run strictly in order)
     # the adjacency / eigenstep stream gets the HIGH priority: a chain of ~3600 small dependent launches per window,
     # each of which would otherwise queue behind a full wave of sketch workgroups
     hi_main = os.environ.get('MUSED_BENCH_PRIO', 'main') == 'main'
-    st_sketch, st_main = torch.cuda.Stream(priority=0 if hi_main else -1), torch.cuda.Stream(priority=-1 if hi_main else 0)
+    st_main = torch.cuda.Stream(priority=-1 if hi_main else 0)
+    st_sketch = [torch.cuda.Stream(priority=0 if hi_main else -1) for _ in sketches]
     pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=False, async_labels=True, stream=st_main)
     torch.cuda.synchronize()
 
     import threading
 
-    sk_events = {}
+    sk_events = {}   # (group, t) -> (event, enqueue time)
     sk_out = {}
+    refs = [{"ev": None, "t": 0.0} for _ in sketches]
 
-    ref = {"ev": None, "t": 0.0}
-
-    def drive_sketch(lo, hi):
-        if sketch is None:
-            return
+    def drive_sketch(g, lo, hi):
         torch.cuda.set_device(local_rank)  # the current device is per host thread
-        with torch.cuda.stream(st_sketch):
+        ref = refs[g]
+        l0, l1 = grp[g]
+        with torch.cuda.stream(st_sketch[g]):
             ref["ev"] = torch.cuda.Event(enable_timing=True)
             ref["ev"].record()
             ref["t"] = time.perf_counter()
             for t in range(lo, hi):
                 t_enq = time.perf_counter()
-                sketch.fit_lanes(rows_all[:, t])
-                sk_out[t] = sketch.get_device()
+                sketches[g].fit_lanes(rows_all[l0:l1, t])
+                sk_out[(g, t)] = sketches[g].get_device()
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
-                sk_events[t] = (ev, t_enq)
+                sk_events[(g, t)] = (ev, t_enq)
             if hi > lo:
-                sk_events[hi - 1][0].synchronize()
+                sk_events[(g, hi - 1)][0].synchronize()
         if os.environ.get("MUSED_BENCH_TRACE"):
-            print(f"[trace] sketch thread done {time.perf_counter() - ref['t']:.3f}s after its start", file=sys.stderr)
+            print(f"[trace] sketch group {g} done {time.perf_counter() - ref['t']:.3f}s after its start", file=sys.stderr)
 
     def drive_main(lo, hi):
         # window order of the label chain: lane-major within the rank is restored after the run
@@ -294,7 +307,8 @@ def main():
                   f" kmeans ms {[round(x) for x in pipe.host_ms['kmeans'][-B:]]} match ms {[round(x) for x in pipe.host_ms['match'][-B:]]}", file=sys.stderr)
 
     def run_range(lo, hi):
-        ths = [threading.Thread(target=drive_sketch, args=(lo, hi)), threading.Thread(target=drive_main, args=(lo, hi))]
+        ths = [threading.Thread(target=drive_sketch, args=(g, lo, hi)) for g in range(len(sketches))]
+        ths.append(threading.Thread(target=drive_main, args=(lo, hi)))
         for th in ths:
             th.start()
         for th in ths:
@@ -303,8 +317,8 @@ def main():
     run_range(0, Wu)
     n_warm_lat = len(pipe.latencies)
     pipe.eng.score_events = []  # HIP events around every similarity-GEMM launch of the timed region
-    if sketch is not None:
-        sketch.profile(True)    # HIP events around every Jacobi sweep graph of the timed region
+    for sk in sketches:
+        sk.profile(True)        # HIP events around every Jacobi sweep graph of the timed region
 
     if world > 1:
         dist.barrier()
@@ -332,16 +346,20 @@ def main():
 
     if rank == 0:
         lat = np.array(pipe.latencies[n_warm_lat:])
-        if sketch is not None and ref["ev"] is not None:
-            # a window is done when its labels AND its sketch are: take the later one.  Sketch group t
+        if sketches and all(r["ev"] is not None for r in refs):
+            # a window is done when its labels AND its sketch are: take the later one.  Lock-step step t of group g
             # completes at t_ref + elapsed(ref event -> its event); latency counts from its enqueue.
-            sk_done = {t: ref["t"] + ref["ev"].elapsed_time(sk_events[t][0]) * 1e-3 for t in range(Wu, T)}
-            sk_lat = np.array([sk_done[t] - sk_events[t][1] for t in range(Wu, T) for p in range(B) if t < Wu + blks[p]])
+            gof = {p: g for g, (a, b) in enumerate(grp) for p in range(a, b)}
+            sk_done = {(g, t): refs[g]["t"] + refs[g]["ev"].elapsed_time(sk_events[(g, t)][0]) * 1e-3
+                       for g in range(len(sketches)) for t in range(Wu, T)}
+            sk_lat = np.array([sk_done[(gof[p], t)] - sk_events[(gof[p], t)][1]
+                               for t in range(Wu, T) for p in range(B) if t < Wu + blks[p]])
             lat = np.maximum(lat, sk_lat) if len(lat) == len(sk_lat) else lat
         ev_pairs = pipe.eng.score_events
         pipe.eng.score_events = None
         gemm_live_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None
-        stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all)
+        stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all[grp[0][0]:grp[0][1]] if grp else rows_all)
+        stages["swfd_groups"] = [b - a for a, b in grp]
         stages["scores_gemm_ms_live_timed_region"] = gemm_live_ms
         # ---- rooflines (both measured live with HIP events on the launch streams over the timed region) ----
         # (1) dominant kernel by time: osjw_kernel, one block-pair round of the one-sided Jacobi of the FD
@@ -349,25 +367,36 @@ def main():
         #     (16 n^2 B per matrix): load/store phases around a VALU-issue-bound chain of
         #     32 (round 0: 63) dependent pair-steps.
         roof = None
-        if sketch is not None:
-            osj_ms, osj_launches, osj_bytes = sketch.profile_read()
-            sketch.profile(False)
+        if sketches:
+            # all groups together: average duration and average algorithmic bytes of ONE launch (what rocprofv3 --stats
+            # averages too).  With G groups on G streams up to G such launches share the GPU at any time, so the
+            # per-launch rate is about 1 / G of what the kernel sustains across the streams (`achieved_all_streams`).
+            osj_ms = osj_launches = 0
+            osj_total_bytes = 0.0
+            for sk in sketches:
+                ms_g, n_g, b_g = sk.profile_read()
+                sk.profile(False)
+                osj_ms += ms_g
+                osj_launches += n_g
+                osj_total_bytes += n_g * b_g
             if osj_launches:
                 osj_us = 1e3 * osj_ms / osj_launches
+                osj_bytes = osj_total_bytes / osj_launches
                 gbs = osj_bytes / (osj_us * 1e-6) / 1e9
+                mats_per_launch = np.mean([sk.lanes * 2 * sk.L for sk in sketches])
+                per_matrix = 16.0 * (2 * ell) ** 2          # every matrix read + written once per launch
+                active_mats = osj_bytes / per_matrix        # < matrices per launch: adaptive sweep count
                 tr = None
-                full_bytes = 16.0 * sketch.lanes * 2 * sketch.L * (2 * ell) ** 2   # every matrix read + written once
-                active_frac = osj_bytes / full_bytes    # < 1: adaptive sweep count, late launches find fewer matrices
                 try:
-                    if args.workload == "c2":
+                    if args.workload == "c2":   # PMC passes: every matrix active in every launch -> bytes per matrix
                         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_osj.json")))
-                        if pm.get("lanes") == B:   # PMC passes ran with every matrix active in every launch
-                            tr = pm["traffic_bytes_per_launch"] * active_frac
+                        tr = pm["traffic_bytes_per_launch"] / pm["matrices_per_launch"] * active_mats
                 except Exception:
                     tr = None
                 roof = {
                     "kernel": f"osjw_kernel<{2 * ell // 64}> (block-pair round of the one-sided Jacobi of the FD rotation, "
-                              f"{sketch.lanes * 2 * sketch.L} Gram matrices of order {2 * ell} per launch)",
+                              f"{mats_per_launch:.0f} Gram matrices of order {2 * ell} per launch, "
+                              f"{len(sketches)} independent launch streams)",
                     "bound": "hbm",
                     "achieved": gbs,
                     "peak": 8000.0,
@@ -377,7 +406,32 @@ def main():
                     "launch_us": osj_us,
                     "launches_timed": osj_launches,
                     "algorithmic_bytes_per_launch": osj_bytes,
-                    "matrices_active_per_launch_avg": active_frac * sketch.lanes * 2 * sketch.L,
+                    "matrices_active_per_launch_avg": active_mats,
+                    "concurrent_launch_streams": len(sketches),
+                    "achieved_all_streams": gbs * len(sketches),
+                }
+        # (1b) the same kernel with the GPU to itself: ONE sketch of all B lanes, nothing else running (outside the timed
+        #      region).  This is the figure that describes the kernel; (1) describes it while it shares the GPU with the
+        #      other group's launches and the adjacency / eigenstep stream.
+        roof_iso = None
+        if sketches and len(sketches) > 1 and not os.environ.get("MUSED_BENCH_NO_ISOLATED"):
+            from mused_amd.swfd import SeqBasedSWFD
+
+            torch.cuda.synchronize()
+            iso = SeqBasedSWFD(N=W, R=sketches[0].R, d=d, sketch_dim=ell, lanes=B)
+            iso.fit_lanes(rows_all[:, 0, : 2 * ell])      # two rotations of warm-up (graph upload, clocks)
+            iso.profile(True)
+            iso.fit_lanes(rows_all[:, -1, 2 * ell:])
+            ms_i, n_i, b_i = iso.profile_read()
+            iso.profile(False)
+            iso.close()
+            if n_i:
+                us_i = 1e3 * ms_i / n_i
+                roof_iso = {
+                    "kernel": f"osjw_kernel<{2 * ell // 64}>, {B * 2 * sketches[0].L} matrices per launch, one launch stream, GPU otherwise idle",
+                    "bound": "hbm", "achieved": b_i / (us_i * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": b_i / (us_i * 1e-6) / 1e9 / 8000.0, "launch_us": us_i, "launches_timed": n_i,
+                    "algorithmic_bytes_per_launch": b_i,
                 }
         # (2) the contraction kernel: similarity GEMM X X^T on fp64 MFMA
         flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
@@ -429,6 +483,7 @@ def main():
             "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
             "stages_ms": stages,
             "roofline": roof,
+            "roofline_isolated": roof_iso,
             "roofline_mfma": roof_gemm,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -437,8 +492,8 @@ def main():
             res["cpu_baseline"] = None
         print(json.dumps(res))
     pipe.close()
-    if sketch is not None:
-        sketch.close()
+    for sk in sketches:
+        sk.close()
     if world > 1:
         dist.destroy_process_group()
 
