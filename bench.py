@@ -394,7 +394,7 @@ def main():
                 except Exception:
                     tr = None
                 roof = {
-                    "kernel": f"osjw_kernel<{2 * ell // 64}> (block-pair round of the one-sided Jacobi of the FD rotation, "
+                    "kernel": f"osjw_kernel<{max(1, -(-2 * ell // 64))}> (block-pair round of the one-sided Jacobi of the FD rotation, "
                               f"{mats_per_launch:.0f} Gram matrices of order {2 * ell} per launch, "
                               f"{len(sketches)} independent launch streams)",
                     "bound": "hbm",
@@ -428,7 +428,7 @@ def main():
             if n_i:
                 us_i = 1e3 * ms_i / n_i
                 roof_iso = {
-                    "kernel": f"osjw_kernel<{2 * ell // 64}>, {B * 2 * sketches[0].L} matrices per launch, one launch stream, GPU otherwise idle",
+                    "kernel": f"osjw_kernel<{max(1, -(-2 * ell // 64))}>, {B * 2 * sketches[0].L} matrices per launch, one launch stream, GPU otherwise idle",
                     "bound": "hbm", "achieved": b_i / (us_i * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": b_i / (us_i * 1e-6) / 1e9 / 8000.0, "launch_us": us_i, "launches_timed": n_i,
                     "algorithmic_bytes_per_launch": b_i,
