@@ -37,6 +37,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration `metric` is quoted on
     "c2": dict(W=10000, d=1024, ell=128, k=50, name="synthetic d=1024 l=128 window=10000 k=50 (BASELINE config 2)"),
+    # BASELINE.json configs[2] (secondary: the order-512 / 1024 eigenproblems still run on the row-per-thread kernel)
+    "c3": dict(W=10000, d=4096, ell=256, k=50, name="synthetic d=4096 l=256 window=10000 k=50 (BASELINE config 3)"),
     # small plumbing case (configs[0] shapes) for quick checks
     "c1": dict(W=500, d=64, ell=16, k=50, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
 }

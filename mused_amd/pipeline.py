@@ -56,12 +56,17 @@ class StreamPipeline:
         # scikit-learn's k-means takes one OpenMP thread per visible core; on a many-core host (256 on the MI355X
         # boxes) that is ~3x slower for a (10k, 128) problem than a handful of threads
         self._omp_limit = None
+        self._blas_limit = None
         try:
             from threadpoolctl import threadpool_limits
 
             want = int(os.environ.get("MUSED_LABEL_THREADS", "8"))
             if want > 0 and (os.cpu_count() or 1) > want:
                 self._omp_limit = threadpool_limits(limits=want, user_api="openmp")
+            # k-means calls BLAS from inside its OpenMP loops and caps it at one thread around them -- by flipping
+            # the process-wide BLAS pool size, which several k-means workers do concurrently and out of step
+            # (OpenBLAS then warns "Detect OpenMP Loop and this application may hang"): pin it at one thread here
+            self._blas_limit = threadpool_limits(limits=1, user_api="blas") if nk > 1 and async_labels else None
         except Exception:  # threadpoolctl missing: keep the library default
             self._omp_limit = None
         self._pending = deque()
@@ -196,9 +201,10 @@ class StreamPipeline:
         for s in (self.swfd, self.fswfd):
             if s is not None:
                 s.close()
-        if self._omp_limit is not None:
-            self._omp_limit.restore_original_limits()
-            self._omp_limit = None
+        for lim in (self._blas_limit, self._omp_limit):
+            if lim is not None:
+                lim.restore_original_limits()
+        self._blas_limit = self._omp_limit = None
 
 
 def process_streaming_data(results, data_modalities, modality_types, window_size, reduced_dim, k_basis, n_clusters_total,
