@@ -228,7 +228,19 @@ constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR2
 
 template <int N>
 __device__ __forceinline__ double wave_treduce(double (&v)[N], int lane, int& idx) {
-  static_assert(N == 8 || N == 16 || N == 32 || N == 64, "wave_treduce: N must be 8, 16, 32 or 64");
+  static_assert(N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "wave_treduce: N must be 4, 8, 16, 32 or 64");
+  if constexpr (N == 4) {
+    // two halving stages (l ^ 32, l ^ 16), then the 16 lanes of a row are summed: idx = (bit 5, bit 4)
+    v[0] = swap32_add(v[0], v[2]);
+    v[1] = swap32_add(v[1], v[3]);
+    double t4 = swap16_add(v[0], v[1]);
+    t4 = t4 + dpp_mov_f64<DPP_ROW_MIRROR>(t4);
+    t4 = t4 + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(t4);
+    t4 = t4 + dpp_mov_f64<DPP_QUAD_XOR2>(t4);
+    t4 = t4 + dpp_mov_f64<DPP_QUAD_XOR1>(t4);
+    idx = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
+    return t4;
+  } else {
   // stage 1: l ^ 32 (N -> N/2)
 #pragma unroll
   for (int i = 0; i < N / 2; ++i) v[i] = swap32_add(v[i], v[i + N / 2]);
@@ -289,6 +301,7 @@ __device__ __forceinline__ double wave_treduce(double (&v)[N], int lane, int& id
   }
   idx = id;
   return t;
+  }
 }
 
 __device__ __forceinline__ double osj_readlane(double v, int l) {
@@ -558,38 +571,42 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
 //                B: w0<->w2, w1<->w3               -> (0,7)(1,6)(4,3)(5,2)
 //                swap w2,w3; B ring w <- w+1       -> (0,6)(1,4)(3,5)(2,7) -> (0,4)(1,5)(3,7)(2,6) -> (0,5)(1,7)(3,6)(2,4)
 //     round r :  (0,4)(1,5)(2,6)(3,7), then three times B ring w <- w+1.
-constexpr int OSJW_SC = 8;   // columns per set
-constexpr int OSJW_NW = 4;   // waves per workgroup
+// SC = columns per set, NW = OSJ_CB / SC = waves per workgroup.  Orders <= 256: SC = 8, NW = 4 (all of the above).
+// Orders 320-512 hold 5-8 rows per lane, so a wave can keep only 2 x 4 columns: SC = 4, NW = 8, 4 pairs per step,
+// 8 phases of 4 steps per block-pair round; the pairs inside the blocks are left to the row-per-thread kernel's
+// intra-block launch (PREFIX is only built for SC = 8).
 
-template <int RP>
+template <int RP, int SC>
 struct OsjwShared {
-  double xfer[OSJW_NW][OSJW_SC * RP][64];  // one set per wave in flight
-  double xnrm[OSJW_NW][OSJW_SC];
-  int xid[OSJW_NW];
-  double nrm[OSJW_NW][2 * OSJW_SC];  // true squared norms of the wave's 16 columns
-  double dsc[OSJW_NW][2 * OSJW_SC];  // column scales d_j (column held as d_j * x_j)
-  double isc[OSJW_NW][2 * OSJW_SC];  // 1 / d_j
-  double2 tau[OSJW_NW][OSJW_SC];
+  static constexpr int NW = OSJ_CB / SC;
+  double xfer[NW][SC * RP][64];  // one set per wave in flight
+  double xnrm[NW][SC];
+  int xid[NW];
+  double nrm[NW][2 * SC];  // true squared norms of the wave's 16 columns
+  double dsc[NW][2 * SC];  // column scales d_j (column held as d_j * x_j)
+  double isc[NW][2 * SC];  // 1 / d_j
+  double2 tau[NW][SC];
 };
 
 // one step: 8 disjoint pairs (P(k), Q(k)) of the wave's 16 columns (compile-time indices)
-template <int RP, bool INTRA, int T>
-__device__ __forceinline__ void osjw_step(double (&x)[2 * OSJW_SC * RP], OsjwShared<RP>& sh, int wave, int lane,
+template <int RP, int SC, bool INTRA, int T>
+__device__ __forceinline__ void osjw_step(double (&x)[2 * SC * RP], OsjwShared<RP, SC>& sh, int wave, int lane,
                                           double small2, int& active) {
-  constexpr int SC = OSJW_SC;
-  auto P = [](int k) constexpr { return INTRA ? (k / 4) * SC + osj_pair_p(SC, T, k % 4) : k; };
-  auto Q = [](int k) constexpr { return INTRA ? (k / 4) * SC + osj_pair_q(SC, T, k % 4) : SC + (k + T) % SC; };
+  constexpr int H = SC / 2;  // pairs inside one set per intra step
+  auto P = [](int k) constexpr { return INTRA ? (k / H) * SC + osj_pair_p(SC, T, k % H) : k; };
+  auto Q = [](int k) constexpr { return INTRA ? (k / H) * SC + osj_pair_q(SC, T, k % H) : SC + (k + T) % SC; };
   // this lane's pair (known before the dot products: the reads of its scalars overlap them)
-  const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);  // as wave_treduce<8> deals them
+  const int idx = (SC == 8) ? ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)
+                            : ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);  // as wave_treduce<SC> deals them
   int lp, lq;
   int tv = T;  // opaque copy: the (lane-dependent) LDS addresses are recomputed per step (3 VALU ops) instead
   asm volatile("" : "+s"(tv));  //   of being kept alive -- and spilled -- across the phases of a launch
   if (INTRA) {
-    const int m = SC - 1, kk = idx & 3;
+    const int m = SC - 1, kk = idx % H;
     const int a = (kk == 0) ? m : (tv + kk) % m;
     const int b = (kk == 0) ? (tv % m) : ((tv - kk + m) % m);
-    lp = (idx >> 2) * SC + (a < b ? a : b);
-    lq = (idx >> 2) * SC + (a < b ? b : a);
+    lp = (idx / H) * SC + (a < b ? a : b);
+    lq = (idx / H) * SC + (a < b ? b : a);
   } else {
     lp = idx;
     lq = SC + ((idx + tv) & (SC - 1));
@@ -616,7 +633,7 @@ __device__ __forceinline__ void osjw_step(double (&x)[2 * OSJW_SC * RP], OsjwSha
     double c, tt, npp, nqq;
     osj_rotation_t(pp, qq, pq, c, tt, npp, nqq);
     const double ic = c * fma(tt, tt, 1.0);  // 1 / c
-    if ((lane & 7) == 0) {
+    if ((lane & (64 / SC - 1)) == 0) {
       sh.nrm[wave][lp] = npp;
       sh.nrm[wave][lq] = nqq;
       sh.dsc[wave][lp] = dp * c;
@@ -641,21 +658,20 @@ __device__ __forceinline__ void osjw_step(double (&x)[2 * OSJW_SC * RP], OsjwSha
   }
 }
 
-template <int RP, bool INTRA, int T = 0>
-__device__ __forceinline__ void osjw_phase(double (&x)[2 * OSJW_SC * RP], OsjwShared<RP>& sh, int wave, int lane,
+template <int RP, int SC, bool INTRA, int T = 0>
+__device__ __forceinline__ void osjw_phase(double (&x)[2 * SC * RP], OsjwShared<RP, SC>& sh, int wave, int lane,
                                            double small2, int& active) {
-  constexpr int NSTEP = INTRA ? OSJW_SC - 1 : OSJW_SC;
+  constexpr int NSTEP = INTRA ? SC - 1 : SC;
   if constexpr (T < NSTEP) {
-    osjw_step<RP, INTRA, T>(x, sh, wave, lane, small2, active);
-    osjw_phase<RP, INTRA, T + 1>(x, sh, wave, lane, small2, active);
+    osjw_step<RP, SC, INTRA, T>(x, sh, wave, lane, small2, active);
+    osjw_phase<RP, SC, INTRA, T + 1>(x, sh, wave, lane, small2, active);
   }
 }
 
 // re-deal: (optionally swap the wave's slots,) hand slot B to LDS and take the set wave `src` handed in
-template <int RP>
-__device__ __forceinline__ void osjw_deal(double (&x)[2 * OSJW_SC * RP], OsjwShared<RP>& sh, int wave, int lane,
+template <int RP, int SC>
+__device__ __forceinline__ void osjw_deal(double (&x)[2 * SC * RP], OsjwShared<RP, SC>& sh, int wave, int lane,
                                           bool do_swap, int src, int& ida, int& idb) {
-  constexpr int SC = OSJW_SC;
   if (do_swap) {  // wave-uniform
 #pragma unroll
     for (int e = 0; e < SC * RP; ++e) {
@@ -696,18 +712,21 @@ __device__ __forceinline__ void osjw_deal(double (&x)[2 * OSJW_SC * RP], OsjwSha
   __syncthreads();  // everyone has taken its set: the buffers may be written again
 }
 
-template <int RP, bool PREFIX>
-__global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb, int round,
-                                                           int* __restrict__ notconv, int sweep,
-                                                           const double* __restrict__ trace, int sortcols) {
+template <int RP, int SC, bool PREFIX>
+__global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb,
+                                                                                  int round,
+                                                                                  int* __restrict__ notconv, int sweep,
+                                                                                  const double* __restrict__ trace,
+                                                                                  int sortcols) {
+  static_assert(!PREFIX || SC == 8, "the in-launch intra-block schedule exists for 8-column sets only");
   if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
   double small2 = notconv ? 0.0 : -1.0;
   if (trace) {
     const double tr = trace[blockIdx.y];
     small2 = 1e-24 * tr * tr;
   }
-  constexpr int SC = OSJW_SC, CB = OSJ_CB;
-  __shared__ OsjwShared<RP> sh;
+  constexpr int CB = OSJ_CB, NW = OSJ_CB / SC;
+  __shared__ OsjwShared<RP, SC> sh;
   double* M = Gc + (long)blockIdx.y * ldn * ldn;
   int bp, bq;
   {
@@ -718,8 +737,9 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
     bq = a < b ? b : a;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int ida = PREFIX ? 2 * wave : wave, idb = PREFIX ? 2 * wave + 1 : 4 + wave;
-  auto set_col = [&](int sid) { return (sid < 4 ? bp * CB + SC * sid : bq * CB + SC * (sid - 4)); };
+  // sets 0 .. NW-1 = columns of block bp, NW .. 2NW-1 = block bq
+  int ida = PREFIX ? 2 * wave : wave, idb = PREFIX ? 2 * wave + 1 : NW + wave;
+  auto set_col = [&](int sid) { return (sid < NW ? bp * CB + SC * sid : bq * CB + SC * (sid - NW)); };
   double x[2 * SC * RP];
   {
     const int ca = set_col(ida), cb = set_col(idb);
@@ -731,7 +751,7 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
         x[(SC + j) * RP + i] = M[(long)(cb + j) * ldn + lane + 64 * i];
       }
   }
-  {  // squared norms of the wave's 16 columns
+  {  // squared norms of the wave's 2 SC columns
     double sq[2 * SC];
 #pragma unroll
     for (int c = 0; c < 2 * SC; ++c) {
@@ -742,7 +762,7 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
     }
     int idx;
     const double t = wave_treduce<2 * SC>(sq, lane, idx);
-    if ((lane & 3) == 0) {
+    if ((lane & (64 / (2 * SC) - 1)) == 0) {
       sh.nrm[wave][idx] = t;
       sh.dsc[wave][idx] = 1.0;
       sh.isc[wave][idx] = 1.0;
@@ -750,31 +770,36 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
   }
   int active = 0;
   if constexpr (PREFIX) {
-    osjw_phase<RP, true>(x, sh, wave, lane, small2, active);
-    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-    osjw_deal<RP>(x, sh, wave, lane, (wave & 1) != 0, wave ^ 1, ida, idb);
-    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-    osjw_deal<RP>(x, sh, wave, lane, (wave & 1) != 0, wave ^ 1, ida, idb);
-    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-    osjw_deal<RP>(x, sh, wave, lane, false, wave ^ 2, ida, idb);
-    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-    osjw_deal<RP>(x, sh, wave, lane, wave >= 2, (wave + 1) & 3, ida, idb);
+    osjw_phase<RP, SC, true>(x, sh, wave, lane, small2, active);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP, SC>(x, sh, wave, lane, (wave & 1) != 0, wave ^ 1, ida, idb);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP, SC>(x, sh, wave, lane, (wave & 1) != 0, wave ^ 1, ida, idb);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP, SC>(x, sh, wave, lane, false, wave ^ 2, ida, idb);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP, SC>(x, sh, wave, lane, wave >= 2, (wave + 1) & 3, ida, idb);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP, SC>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+    osjw_deal<RP, SC>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
+    osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
   } else {
-    osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-    osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
+    // NW phases (A x B of the wave's two sets), the B sets moving round the ring of waves in between: every set of
+    // bp meets every set of bq.
+#pragma unroll
+    for (int ph = 0; ph < NW; ++ph) {
+      osjw_phase<RP, SC, false>(x, sh, wave, lane, small2, active);
+      if (ph + 1 < NW) osjw_deal<RP, SC>(x, sh, wave, lane, false, (wave + 1) & (NW - 1), ida, idb);
+    }
   }
-  osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-  osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
-  osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
-  osjw_deal<RP>(x, sh, wave, lane, false, (wave + 1) & 3, ida, idb);
-  osjw_phase<RP, false>(x, sh, wave, lane, small2, active);
   if (sortcols && lane == 0) sh.xid[wave] = (ida << 8) | idb;  // (xid is free after the last re-deal)
   if (sortcols) {
     // de Rijk at block-pair level: the 64 columns go back in descending norm (ties: current position).  Costs
     // about one sweep on well-separated spectra and is what makes clustered / multiple eigenvalues converge.
     __syncthreads();  // all waves' norms are final
-    // lane l stands for column (wave l / 16, slot l % 16) of the workgroup: one ballot per own column gives its rank
-    const int ow = lane >> 4, oc = lane & 15;
+    // lane l stands for column (wave l / 2SC, slot l % 2SC) of the workgroup: one ballot per own column gives its rank
+    const int ow = lane / (2 * SC), oc = lane % (2 * SC);
     const double other = sh.nrm[ow][oc];
     const int oid = ((oc < SC) ? (sh.xid[ow] >> 8) : (sh.xid[ow] & 255)) * SC + (oc & (SC - 1));
 #pragma unroll
@@ -802,14 +827,15 @@ __global__ __launch_bounds__(64 * OSJW_NW, 2) void osjw_kernel(double* __restric
   if (notconv && __any(active) && lane == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
 }
 
+// orders <= 256: round 0 carries the pairs inside the blocks, nb - 1 launches per sweep
 template <int RP>
 static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB;
   const int so = sweep >= p->sort_from ? 1 : 0;
-  hipLaunchKernelGGL((osjw_kernel<RP, true>), dim3(nb / 2, p->batch), dim3(64 * OSJW_NW), 0, st, p->Gc, p->ldn, nb, 0,
+  hipLaunchKernelGGL((osjw_kernel<RP, 8, true>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb, 0,
                      p->notconv, sweep, p->trace, so);
   for (int round = 1; round < nb - 1; ++round)
-    hipLaunchKernelGGL((osjw_kernel<RP, false>), dim3(nb / 2, p->batch), dim3(64 * OSJW_NW), 0, st, p->Gc, p->ldn, nb,
+    hipLaunchKernelGGL((osjw_kernel<RP, 8, false>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb,
                        round, p->notconv, sweep, p->trace, so);
 }
 
@@ -871,6 +897,20 @@ __global__ void osj_extract_kernel(const double* __restrict__ Gc, const double* 
   if (V) V[(long)b * n * n + (long)a * n + j] = (l > 0.0) ? Gc[((long)b * ldn + j) * ldn + a] / l : 0.0;
 }
 
+// orders 320-512: pairs inside the blocks by the row-per-thread kernel (NT = ldn threads), then all nb - 1
+// block-pair rounds by the wave-private kernel with 4-column sets (8 waves)
+template <int NT>
+static void osjw4_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
+  constexpr int RP = NT / 64;
+  const int nb = p->ldn / OSJ_CB;
+  hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
+                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols);
+  const int so = sweep >= p->sort_from ? 1 : 0;
+  for (int round = 0; round < nb - 1; ++round)
+    hipLaunchKernelGGL((osjw_kernel<RP, 4, false>), dim3(nb / 2, p->batch), dim3(512), 0, st, p->Gc, p->ldn, nb, round,
+                       p->notconv, sweep, p->trace, so);
+}
+
 template <int NT>
 static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   // one sweep = every column pair exactly once: one INTRA launch (pairs inside each group of 2*CB
@@ -894,7 +934,11 @@ static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
         case 64: osjw_launch_sweep<1>(p, sw, st); break;
         case 128: osjw_launch_sweep<2>(p, sw, st); break;
         case 192: osjw_launch_sweep<3>(p, sw, st); break;
-        default: osjw_launch_sweep<4>(p, sw, st); break;
+        case 256: osjw_launch_sweep<4>(p, sw, st); break;
+        case 320: osjw4_launch_sweep<320>(p, sw, st); break;
+        case 384: osjw4_launch_sweep<384>(p, sw, st); break;
+        case 448: osjw4_launch_sweep<448>(p, sw, st); break;
+        default: osjw4_launch_sweep<512>(p, sw, st); break;
       }
       continue;
     }
@@ -958,7 +1002,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out)
     const char* sf = getenv("MUSED_OSJ_SORT_FROM");
     p->sort_from = sf ? atoi(sf) : 0;
     const char* wk = getenv("MUSED_OSJ_WAVE");  // 0: row-per-thread kernel for every order
-    p->wavek = (p->ldn <= 256 && !(wk && wk[0] == '0')) ? 1 : 0;
+    p->wavek = (p->ldn <= 512 && !(wk && wk[0] == '0')) ? 1 : 0;
     const char* so = getenv("MUSED_OSJ_SORT");
     p->sortcols = (so && so[0] == '0') ? 0 : 1;  // row-per-thread kernel only: helps on rank-deficient matrices
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
@@ -1055,7 +1099,7 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
   }
   const int nb = p->ldn / OSJ_CB;
   // per sweep: (nb - 1) block-pair rounds, plus one launch for the pairs inside the blocks in the row-per-thread kernel
-  *launches = (long)p->prof_n * p->sweeps * (p->wavek ? nb - 1 : nb);
+  *launches = (long)p->prof_n * p->sweeps * ((p->wavek && p->ldn <= 256) ? nb - 1 : nb);
   // a launch reads and writes every element of every matrix that is still iterating; with the adaptive sweep
   // count the launches of later sweeps find fewer (or no) such matrices: average over the launches timed
   double frac = 1.0;
