@@ -325,7 +325,7 @@ def test_syevj(L, n, batch, sweeps):
         assert not V[b][:, ~nz].any() or np.abs(ev[b][~nz]).max() <= 1e-9 * scale
 
 
-@pytest.mark.parametrize("n", [64, 192, 256, 512])
+@pytest.mark.parametrize("n", [64, 192, 256, 320, 448, 512])
 def test_syevj_special_matrices(L, n):
     """Degenerate inputs of the adaptive one-sided solver: zero matrix, diagonal, rank one, a multiple
     eigenvalue, heavy rank deficiency (rank n/3, dense) -- eigenvalues to 1e-12 of the largest one within the
