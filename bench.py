@@ -436,7 +436,12 @@ def main():
                     "algorithmic_bytes_per_launch": b_i,
                 }
         # (2) the contraction kernel: similarity GEMM X X^T on fp64 MFMA
-        flops = 2.0 * W * W * d  # similarity = 2 W d flop per row x W rows per launch
+        # SURVEY 8(d) counts 2 W d flop per row x W rows; the kernel computes the tiles on or above the diagonal only
+        # (the distance / cosine epilogue is symmetric) and writes each of them twice: `achieved` is priced on the MFMA
+        # work actually executed, `algorithmic_flops_per_launch` keeps the SURVEY figure
+        flops = 2.0 * W * W * d
+        nt = -(-W // 128)
+        flops_exec = 2.0 * d * 128.0 * 128.0 * (nt * (nt + 1) // 2)
         gemm_ms = gemm_live_ms if gemm_live_ms else stages["scores_gemm_ms"]
         gemm_s = gemm_ms * 1e-3
         traffic = None
@@ -447,16 +452,19 @@ def main():
         except Exception:
             traffic = None
         roof_gemm = {
-            "kernel": "gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64)",
+            "kernel": "gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64, "
+                      "upper-triangular tiles + mirrored stores)",
             "bound": "mfma",
-            "achieved": flops / gemm_s / 1e12,
+            "achieved": flops_exec / gemm_s / 1e12,
             "peak": 78.6,
             "unit": "TFLOP/s",
-            "frac": flops / gemm_s / 1e12 / 78.6,
+            "frac": flops_exec / gemm_s / 1e12 / 78.6,
             "traffic": traffic,
             "launch_ms": gemm_ms,
             "launch_ms_standalone": stages["scores_gemm_ms"],
+            "executed_flops_per_launch": flops_exec,
             "algorithmic_flops_per_launch": flops,
+            "algorithmic_tflops_equivalent": flops / gemm_s / 1e12,
         }
         if roof is None:
             roof = roof_gemm

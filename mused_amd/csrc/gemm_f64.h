@@ -39,6 +39,8 @@ struct GemmArgs {
   int kchunk;  // split-K: batch index z covers k in [z*kchunk, min(K,(z+1)*kchunk)) when splitk != 0
   int splitk;
   int tiles_m, tiles_n;
+  int sym;  // C = A A^T (A == B, M == N) with a symmetric epilogue: only tiles on or above the diagonal are computed,
+            // each off-diagonal tile is also written mirrored (epi(z, col, row, v)): half the MFMA work
 };
 
 // ---- staging -------------------------------------------------------------
@@ -145,19 +147,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
   double* Bs = smem + 2 * GEMM_BK * GEMM_LD;         // [2][BK][LD]
 
   const int z = blockIdx.z;
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  // grouped tile order: consecutive workgroup ids (one XCD, dispatched together) cover 8 tile-rows x 8
-  // tile-columns, so that the ~64 tiles in flight on an XCD re-use 8 A row-panels and 8 B column-panels
-  // out of its L2 instead of streaming 64 different B panels from the Infinity Cache
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * g.tiles_n;
-  const int group_id = wg / per_group;
-  const int first_m = group_id * GROUP_M;
-  const int group_size = min(g.tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (wg % group_size);
-  const int tn = (wg % per_group) / group_size;
+  int tm, tn;
+  if (g.sym) {
+    // C = A A^T with a symmetric epilogue: the grid holds the tiles on or above the diagonal only, row-major over
+    // the triangle (consecutive workgroups of an XCD share the A row-panel); row tm starts at
+    // e0(tm) = tm * tiles - tm (tm - 1) / 2.  Equal tile counts per XCD (a full grid with early exits gives the
+    // XCD that owns the first tile-rows twice the average work).
+    const int t = g.tiles_n, nwg = t * (t + 1) / 2;
+    const int e = xcd_remap(blockIdx.x, nwg);
+    int r = (int)((2.0 * t + 1.0 - sqrt((2.0 * t + 1.0) * (2.0 * t + 1.0) - 8.0 * e)) * 0.5);
+    r = r < 0 ? 0 : (r > t - 1 ? t - 1 : r);
+    while (r > 0 && r * t - r * (r - 1) / 2 > e) --r;
+    while (r + 1 < t && (r + 1) * t - (r + 1) * r / 2 <= e) ++r;
+    tm = r;
+    tn = r + (e - (r * t - r * (r - 1) / 2));
+  } else {
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    // grouped tile order: consecutive workgroup ids (one XCD, dispatched together) cover 8 tile-rows x 8
+    // tile-columns, so that the ~64 tiles in flight on an XCD re-use 8 A row-panels and 8 B column-panels
+    // out of its L2 instead of streaming 64 different B panels from the Infinity Cache
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int group_id = wg / per_group;
+    const int first_m = group_id * GROUP_M;
+    const int group_size = min(g.tiles_m - first_m, GROUP_M);
+    tm = first_m + (wg % group_size);
+    tn = (wg % per_group) / group_size;
+  }
   const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+  const bool mirror = g.sym && tm != tn;
 
   int k_lo = 0, k_hi = g.K;
   const TA* A = reinterpret_cast<const TA*>(g.A);
@@ -241,6 +260,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
       }
     }
   }
+  if (mirror) {
+    // the same 64 x 64 block of the wave, written to (col, row): transposed through a wave-private LDS patch
+    // (32 columns at a time, pitch 65) so that every store instruction writes 512 contiguous bytes of one row
+    __syncthreads();  // all waves are done with the operand buffers
+    double* patch = smem + wave * (32 * 65);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = half * 2 + jj;
+          const int col = n0 + wc * 64 + j * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = i * 16 + kq + 4 * r;
+            // entry (col, row) of the result: evaluated in ITS orientation (the epilogue need not be commutative)
+            const int rg = m0 + wr * 64 + rl;
+            patch[(jj * 16 + li) * 65 + rl] = (rg < g.M && col < g.N) ? epi.value(col, rg, acc[i][j][r]) : 0.0;
+          }
+        }
+      // wave-private patch: LDS operations of one wave complete in order, no barrier
+      const int rowm = m0 + wr * 64 + lane;
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) {
+        const int colm = n0 + wc * 64 + half * 32 + c;
+        if (colm < g.N && rowm < g.M) epi.put(z, colm, rowm, patch[c * 65 + lane]);
+      }
+    }
+  }
 }
 
 // ---- plain epilogue --------------------------------------------------------
@@ -251,6 +300,11 @@ struct EpiStore {
   double alpha;
   __device__ __forceinline__ void operator()(int z, int row, int col, double v) const {
     C[(long)z * strideC + (long)row * ldc + col] = alpha * v;
+  }
+  // symmetric launches: value(row, col, v) is what operator() would store, put() stores it somewhere else
+  __device__ __forceinline__ double value(int, int, double v) const { return alpha * v; }
+  __device__ __forceinline__ void put(int z, int row, int col, double val) const {
+    C[(long)z * strideC + (long)row * ldc + col] = val;
   }
 };
 
@@ -272,7 +326,7 @@ int gemm_f64_launch_t(GemmArgs g, int batch, Epi epi, bool vec, hipStream_t stre
   g.tiles_m = cdiv(g.M, GEMM_BM);
   g.tiles_n = cdiv(g.N, GEMM_BN);
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return MUSED_OK;
-  dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
+  dim3 grid(g.sym ? g.tiles_n * (g.tiles_n + 1) / 2 : g.tiles_m * g.tiles_n, 1, batch);
   int rc;
   if (vec) {
     if ((rc = gemm_f64_prepare_t<TA, TB, A_KC, B_KC, true, Epi>())) return rc;

@@ -56,9 +56,13 @@ struct EpiSqL2 {
   long ld;
   const double* nrm;  // squared norms
   __device__ __forceinline__ void operator()(int, int row, int col, double v) const {
-    const double dd = nrm[row] - 2.0 * v + nrm[col];
-    S[(long)row * ld + col] = dd > 0.0 ? dd : 0.0;
+    S[(long)row * ld + col] = value(row, col, v);
   }
+  __device__ __forceinline__ double value(int row, int col, double v) const {
+    const double dd = nrm[row] - 2.0 * v + nrm[col];
+    return dd > 0.0 ? dd : 0.0;
+  }
+  __device__ __forceinline__ void put(int, int row, int col, double val) const { S[(long)row * ld + col] = val; }
 };
 
 struct EpiNegCos {
@@ -66,8 +70,10 @@ struct EpiNegCos {
   long ld;
   const double* inv;  // 1 / norm
   __device__ __forceinline__ void operator()(int, int row, int col, double v) const {
-    S[(long)row * ld + col] = -(v * inv[row] * inv[col]);
+    S[(long)row * ld + col] = value(row, col, v);
   }
+  __device__ __forceinline__ double value(int row, int col, double v) const { return -(v * inv[row] * inv[col]); }
+  __device__ __forceinline__ void put(int, int row, int col, double val) const { S[(long)row * ld + col] = val; }
 };
 
 template <typename T>
@@ -78,6 +84,9 @@ static int scores_launch(const T* X, long n, int d, long ld, int metric, double*
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = X; g.B = X; g.lda = ld; g.ldb = ld; g.M = (int)n; g.N = (int)n; g.K = d;
+  // X X^T: the squared-distance / cosine epilogues are symmetric in (row, col) -> upper tiles only, mirrored stores
+  const char* sy = getenv("MUSED_SCORES_SYM");
+  g.sym = (sy && sy[0] == '0') ? 0 : 1;
   const bool vec = vec_ok<T>(X, ld, 0);
   if (metric == 0) {
     EpiSqL2 epi{S, n, norms};
