@@ -33,6 +33,8 @@ int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, cons
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.strideA = strideA; g.strideB = strideB;
   g.M = M; g.N = N; g.K = K; g.splitk = 0; g.kchunk = 0;
+  // Gram products (A A^T: same operand, same layout, square result): tiles on or above the diagonal + mirrored stores
+  g.sym = (A == B && a_kc == b_kc && lda == ldb && strideA == strideB && M == N) ? 1 : 0;
   EpiStore epi{C, ldc, strideC, alpha};
   const bool vec = vec_ok<double>(A, lda, strideA) && vec_ok<double>(B, ldb, strideB);
   if (a_kc && b_kc) return gemm_f64_launch_t<double, double, true, true>(g, batch, epi, vec, stream);
