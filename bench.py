@@ -221,10 +221,11 @@ def main():
     # (mused_swfd_*_lanes) on one HIP stream / host thread; adjacency + eigenstep + labels of the same
     # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
     # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
-    # lanes: at most --lanes; the count that minimises (lock-step steps) x (time of a step of B lanes: measured about
-    # 60 + 74 B ms at config 2 with two sketch groups, i.e. per-lane cost falls with B and 9 lanes fill the GPU).
+    # lanes: at most --lanes; the count that minimises (lock-step steps) x (time of a step of B lanes; measured at
+    # config 2 with two sketch groups: 400 ms at B = 3, 463 at 5, 712 at 9 -- about 250 + 51 B: the per-lane cost falls
+    # with B).
     cand = range(1, max(1, min(args.lanes, K)) + 1)
-    B = min(cand, key=lambda b: ((-(-K // b)) * (60.0 + 74.0 * b), -b))
+    B = min(cand, key=lambda b: ((-(-K // b)) * (250.0 + 51.0 * b), -b))
     blks = [K // B + (1 if p < K % B else 0) for p in range(B)]   # timed windows per lane
     blk = max(blks)
     T = Wu + blk                      # lock-step groups (a lane with fewer windows repeats its last one: padding)
