@@ -412,6 +412,10 @@ def main():
                     "matrices_active_per_launch_avg": active_mats,
                     "concurrent_launch_streams": len(sketches),
                     "achieved_all_streams": gbs * len(sketches),
+                    "frac_all_streams": gbs * len(sketches) / 8000.0,
+                    "note": "per-launch figures as the contract defines them; launches of the two sketch groups (and the "
+                            "adjacency / eigenstep stream) run side by side, so the kernel sustains about "
+                            "`achieved_all_streams`; `roofline_isolated` is the same kernel alone on the GPU",
                 }
         # (1b) the same kernel with the GPU to itself: ONE sketch of all B lanes, nothing else running (outside the timed
         #      region).  This is the figure that describes the kernel; (1) describes it while it shares the GPU with the
