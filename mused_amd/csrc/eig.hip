@@ -28,6 +28,7 @@ struct EigPlan {
   int* notconv;  // OSJ: sweeps x batch convergence flags
   int wavek;     // OSJ: 1 = wave-private kernel (orders <= 256)
   bool direct;   // OSJ: the caller fills Gc itself (n == ldn): no pack pass
+  const int* rep; // optional: matrix b is a duplicate of matrix rep[b] != b and is not solved
   int sortcols;  // OSJ: store columns by descending norm inside each block pair
   int sort_from; // OSJ wave kernel: first sweep that sorts
   double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv / work point into)
@@ -395,7 +396,9 @@ __host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
 template <int CB, int NT, int MODE, int DBG = 0>
 __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
                                                       int* __restrict__ notconv, int sweep,
-                                                      const double* __restrict__ trace, int sortcols) {
+                                                      const double* __restrict__ trace, int sortcols,
+                                                      const int* __restrict__ rep) {
+  if (rep && rep[blockIdx.y] != (int)blockIdx.y) return;  // duplicate of another matrix of the batch
   // ADAPTIVE SWEEPS: notconv[sweep * batch + matrix] is set by any workgroup that met, in this sweep, a
   // column pair that still matters (osj_pair_active) (columns converge
   // to lambda_j u_j: pairs inside the numerical null space never settle in the relative sense and carry
@@ -717,7 +720,9 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
                                                                                   int round,
                                                                                   int* __restrict__ notconv, int sweep,
                                                                                   const double* __restrict__ trace,
-                                                                                  int sortcols) {
+                                                                                  int sortcols,
+                                                                                  const int* __restrict__ rep) {
+  if (rep && rep[blockIdx.y] != (int)blockIdx.y) return;  // duplicate of another matrix of the batch
   static_assert(!PREFIX || SC == 8, "the in-launch intra-block schedule exists for 8-column sets only");
   if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
   double small2 = notconv ? 0.0 : -1.0;
@@ -833,10 +838,10 @@ static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB;
   const int so = sweep >= p->sort_from ? 1 : 0;
   hipLaunchKernelGGL((osjw_kernel<RP, 8, true>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb, 0,
-                     p->notconv, sweep, p->trace, so);
+                     p->notconv, sweep, p->trace, so, p->rep);
   for (int round = 1; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, 8, false>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb,
-                       round, p->notconv, sweep, p->trace, so);
+                       round, p->notconv, sweep, p->trace, so, p->rep);
 }
 
 // G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
@@ -866,11 +871,13 @@ __global__ void osj_begin_kernel(const double* __restrict__ Gc, int ldn, int nfl
 
 // Profiling only: adds the number of (matrix, sweep) pairs that did work in the solve just finished
 // (every matrix runs sweep 0; matrix b runs sweep s > 0 iff sweep s - 1 raised its flag).
-__global__ void osj_count_kernel(const int* __restrict__ notconv, int batch, int sweeps, unsigned long long* __restrict__ acc) {
+__global__ void osj_count_kernel(const int* __restrict__ notconv, int batch, int sweeps, unsigned long long* __restrict__ acc,
+                                 const int* __restrict__ rep) {
   int c = 0;
   for (long i = threadIdx.x; i < (long)batch * (sweeps - 1); i += blockDim.x) c += notconv[i] != 0;
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) c += (!rep || rep[b] == b);  // sweep 0: every solved matrix
   c = (int)wave_sum((double)c);
-  if ((threadIdx.x & 63) == 0) atomicAdd(acc, (unsigned long long)(c + (threadIdx.x == 0 ? batch : 0)));
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, (unsigned long long)c);
 }
 
 // lam[b][j] = |column j| ; one wave per column
@@ -904,11 +911,11 @@ static void osjw4_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   constexpr int RP = NT / 64;
   const int nb = p->ldn / OSJ_CB;
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols);
+                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols, p->rep);
   const int so = sweep >= p->sort_from ? 1 : 0;
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, 4, false>), dim3(nb / 2, p->batch), dim3(512), 0, st, p->Gc, p->ldn, nb, round,
-                       p->notconv, sweep, p->trace, so);
+                       p->notconv, sweep, p->trace, so, p->rep);
 }
 
 template <int NT>
@@ -921,10 +928,10 @@ static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   // rotate the cross pairs of (2b, 2b+1); instead launch MODE 2 with half-size blocks: CB/2 columns per
   // block -> 2*(CB/2) = CB columns per workgroup = exactly one block.
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols);
+                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols, p->rep);
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, NT, 1>), dim3(nb / 2, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                       nb, round, p->notconv, sweep, p->trace, p->sortcols);
+                       nb, round, p->notconv, sweep, p->trace, p->sortcols, p->rep);
 }
 
 static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
@@ -982,11 +989,12 @@ static int enqueue_sweeps(EigPlan* p, hipStream_t st) {
   return cur;
 }
 
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out) {
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep) {
   MUSED_REQUIRE(n >= 2 && n % 2 == 0 && batch >= 1 && sweeps >= 1, "eig_plan_create: n must be even (n=%d)", n);
   EigPlan* p = new EigPlan();
   memset(p, 0, sizeof(*p));
   p->n = n; p->batch = batch; p->sweeps = sweeps;
+  p->rep = rep;
   const char* em = getenv("MUSED_EIG");
   p->method = (em && em[0] == '0') ? 0 : 1;
   if (n > 1024) p->method = 0;
@@ -1154,7 +1162,7 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
       MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
       ++p->prof_n;
       if (p->notconv)
-        hipLaunchKernelGGL(osj_count_kernel, dim3(1), dim3(256), 0, st, p->notconv, p->batch, p->sweeps, p->work);
+        hipLaunchKernelGGL(osj_count_kernel, dim3(1), dim3(256), 0, st, p->notconv, p->batch, p->sweeps, p->work, p->rep);
     }
     hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam);
     if (evals)
@@ -1206,12 +1214,12 @@ int mused_debug_osj_time(const double* init, int batch, int variant, int reps, d
   auto launch = [&](int round) {
     dim3 grid(nb / 2, batch), blk(256);
     switch (variant) {
-      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
-      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
-      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
-      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
-      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1); break;
-      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1);
+      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
+      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr);
     }
   };
   MUSED_CHECK_HIP(hipEventRecord(e0, st));

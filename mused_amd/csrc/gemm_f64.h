@@ -39,6 +39,7 @@ struct GemmArgs {
   int kchunk;  // split-K: batch index z covers k in [z*kchunk, min(K,(z+1)*kchunk)) when splitk != 0
   int splitk;
   int tiles_m, tiles_n;
+  const int* rep;  // optional (batched launches): batch entry z is computed only if rep[z] == z
   int sym;  // C = A A^T (A == B, M == N) with a symmetric epilogue: only tiles on or above the diagonal are computed,
             // each off-diagonal tile is also written mirrored (epi(z, col, row, v)): half the MFMA work
 };
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
   double* Bs = smem + 2 * GEMM_BK * GEMM_LD;         // [2][BK][LD]
 
   const int z = blockIdx.z;
+  if (g.rep && g.rep[z] != z) return;  // a duplicate of entry rep[z]: its consumer reads that one
   int tm, tn;
   if (g.sym) {
     // C = A A^T with a symmetric epilogue: the grid holds the tiles on or above the diagonal only, row-major over

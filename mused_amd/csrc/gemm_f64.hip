@@ -28,11 +28,12 @@ int gemm_f64_prepare_all() {
 
 int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb,
              long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha,
-             hipStream_t stream) {
+             hipStream_t stream, const int* rep) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.strideA = strideA; g.strideB = strideB;
   g.M = M; g.N = N; g.K = K; g.splitk = 0; g.kchunk = 0;
+  g.rep = rep;
   // Gram products (A A^T: same operand, same layout, square result): tiles on or above the diagonal + mirrored stores
   g.sym = (A == B && a_kc == b_kc && lda == ldb && strideA == strideB && M == N) ? 1 : 0;
   EpiStore epi{C, ldc, strideC, alpha};

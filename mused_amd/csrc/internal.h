@@ -8,7 +8,8 @@ namespace mused {
 //   a_kc: A stored [M][K] (true) or [K][M] (false);  b_kc: B stored [N][K] (true) or [K][N] (false).
 int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb,
              long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha,
-             hipStream_t stream);
+             hipStream_t stream, const int* rep = nullptr);
+// rep (device, batch ints, optional): entry z is computed only when rep[z] == z (duplicates are skipped)
 
 // Sets the dynamic-LDS attribute of every plain GEMM instantiation (call before stream capture).
 int gemm_f64_prepare_all();
@@ -39,7 +40,8 @@ int adj_transpose(const unsigned long long* mask, int n, int words, unsigned lon
 struct EigPlan;
 // own_graph: capture the sweep launches into a private hipGraph (set false when the caller
 // captures a larger pipeline that contains this solve).
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out);
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr);
+// rep (device, batch ints, optional, read at every solve): matrix b is solved only when rep[b] == b
 void eig_plan_destroy(EigPlan* p);
 // In: G (batch x n x n, symmetric) is copied into the plan's workspace.  Out: eigenvalues
 // (unsorted, batch x n) and eigenvectors V (batch x n x n, column j <-> eigenvalue j).

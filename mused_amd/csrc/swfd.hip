@@ -34,7 +34,8 @@ struct Swfd {
   double* buf;         // S x n2 x d
   double* queue;       // S x cap x d
   long long* qt;       // S x cap   snapshot timestamps
-  int* meta;           // S x 4     {nk, qhead, qcount, unused}
+  int* meta;           // S x 4     {nk, qhead, qcount, dumps the next level did not make, since the last clear}
+  int* rep;            // S         representative of the sketch's state class for the next rotation (see swfd_rep_kernel)
   long long* dropped;  // S         largest timestamp of a snapshot lost to the ring capacity
   double* theta;       // S
   // rotation workspace
@@ -90,6 +91,26 @@ __global__ void swfd_restart_kernel(double* __restrict__ buf, double* __restrict
 
 __global__ void swfd_set_now_kernel(long long* now, long long v) { *now = v; }
 
+// Sketches of one kind (MAIN or AUX) of one lane see the same rows and differ only in the dump threshold
+// theta_j = 2^j N / l.  Levels j and j + 1 make the same decisions -- and hold bit-identical buffers and snapshot
+// rings -- until a direction falls between their thresholds (theta_j <= s2 < 2 theta_j: dumped at j, kept at j + 1);
+// meta[.][3] counts those events since the sketch was cleared.  rep[s] = the highest level of the run of
+// still-identical levels that starts at s: only representatives get a Gram matrix, an eigen-decomposition and a
+// rotate product; the others read the representative's and apply their own threshold (results unchanged: identical
+// inputs through the same deterministic kernels).  On the 8-blob stream of the benchmark 3 of 28 sketches are
+// duplicates in steady state, 17 of 28 in the first window of a stream.  One thread per (lane, kind).
+__global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains, int* __restrict__ rep) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchains) return;
+  const int base = c * L;  // sketch index = lane * 2L + kind * L + level = chain * L + level
+  int r = base + L - 1;
+  rep[r] = r;
+  for (int j = L - 2; j >= 0; --j) {
+    if (meta[(base + j) * 4 + 3] != 0) r = base + j;
+    rep[base + j] = r;
+  }
+}
+
 // One workgroup per sketch: expiry, eigenvalue ordering, shrink, dump/keep plan, Wc.
 // (evals, U): eigenvalues and eigenvectors, row pitch ldu; cols != 0: U holds the solver's raw columns
 // lam_j u_j (column j contiguous) instead of the eigenvector matrix.
@@ -100,14 +121,15 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
                                                           const double* __restrict__ theta, int* __restrict__ meta,
                                                           long long* __restrict__ qt, long long* __restrict__ dropped,
                                                           int* __restrict__ plan, int* __restrict__ keep_src,
-                                                          double* __restrict__ Wc) {
+                                                          double* __restrict__ Wc, const int* __restrict__ rep) {
   __shared__ double lam[1024];
   __shared__ int order[1024];
   __shared__ double scale[512];  // sqrt(s2 / lam) of the top-l rows (0 = discarded)
   const int s = blockIdx.x, t = threadIdx.x;
   const long long now = *now_p;
-  const double* ev = evals + (long)s * ldu;
-  const double* Us = U + (long)s * ldu * ldu;
+  const int sr = rep ? rep[s] : s;  // whose eigen-decomposition this sketch uses (its own unless it is a duplicate)
+  const double* ev = evals + (long)sr * ldu;
+  const double* Us = U + (long)sr * ldu * ldu;
   if (t < n2) lam[t] = ev[t];
   __syncthreads();
   if (t < n2) {
@@ -121,7 +143,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
   }
   __syncthreads();
   if (t == 0) {
-    int nk = 0, head = meta[s * 4 + 1], cnt = meta[s * 4 + 2];
+    int nk = 0, head = meta[s * 4 + 1], cnt = meta[s * 4 + 2], ndump = 0;
     long long drop = dropped[s];
     long long* q = qt + (long)s * cap;
     while (cnt > 0 && q[head] + N <= now) {  // expiry
@@ -150,6 +172,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
           pos = (head + cnt) % cap;
           q[pos] = now;
           ++cnt;
+          ndump += (s2 < 2.0 * th);  // dumped here but kept one level up: this sketch parts with the next level
           kind = 2;
         } else {
           pos = nk;
@@ -165,9 +188,11 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
     meta[s * 4 + 0] = nk;
     meta[s * 4 + 1] = head;
     meta[s * 4 + 2] = cnt;
+    meta[s * 4 + 3] += ndump;
     dropped[s] = drop;
   }
   __syncthreads();
+  if (sr != s) return;  // the rotate product is taken from the representative
   double* W = Wc + (long)s * ell * n2;
   for (int e = t; e < ell * n2; e += 1024) {
     const int i = e / n2, a = e - i * n2;
@@ -180,9 +205,9 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
 __global__ void swfd_scatter_kernel(const double* __restrict__ T, const int* __restrict__ plan,
                                     const int* __restrict__ keep_src, const int* __restrict__ meta,
                                     double* __restrict__ buf, double* __restrict__ queue, int n2, int ell, int cap,
-                                    int d) {
+                                    int d, const int* __restrict__ rep) {
   const int rho = blockIdx.x, s = blockIdx.y;
-  const double* Ts = T + (long)s * ell * d;
+  const double* Ts = T + (long)(rep ? rep[s] : s) * ell * d;
   if (rho < ell && plan[(s * ell + rho) * 2] == 2) {
     const int slot = plan[(s * ell + rho) * 2 + 1];
     double* dst = queue + ((long)s * cap + slot) * d;
@@ -203,8 +228,10 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
   const int S = h->S, n2 = h->n2, d = h->d, ell = h->ell;
   int rc;
   hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
+  if (h->rep)
+    hipLaunchKernelGGL(swfd_rep_kernel, dim3(cdiv(2 * h->lanes, 64)), dim3(64), 0, st, h->meta, h->L, 2 * h->lanes, h->rep);
   if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
-                     (long)n2 * n2, n2, n2, d, S, 1.0, st)))
+                     (long)n2 * n2, n2, n2, d, S, 1.0, st, h->rep)))
     return rc;
   const double *ecols = nullptr, *elam = nullptr;
   int eld = 0;
@@ -212,12 +239,12 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
   if ((rc = eig_plan_run_inplace(h->eig, raw ? nullptr : h->evals, raw ? nullptr : h->U, st, true))) return rc;
   hipLaunchKernelGGL(swfd_decide_kernel, dim3(S), dim3(1024), 0, st, raw ? elam : h->evals, raw ? ecols : h->U,
                      raw ? eld : n2, raw ? 1 : 0, n2, ell, h->cap, h->N,
-                     h->now_dev, h->theta, h->meta, h->qt, h->dropped, h->plan, h->keep_src, h->Wc);
+                     h->now_dev, h->theta, h->meta, h->qt, h->dropped, h->plan, h->keep_src, h->Wc, h->rep);
   if ((rc = gemm_f64(true, false, h->Wc, n2, (long)ell * n2, h->buf, d, (long)n2 * d, h->T, d, (long)ell * d, ell, d,
-                     n2, S, 1.0, st)))
+                     n2, S, 1.0, st, h->rep)))
     return rc;
   hipLaunchKernelGGL(swfd_scatter_kernel, dim3(n2, S), dim3(256), 0, st, h->T, h->plan, h->keep_src, h->meta, h->buf,
-                     h->queue, n2, ell, h->cap, d);
+                     h->queue, n2, ell, h->cap, d, h->rep);
   MUSED_LAUNCH_CHECK();
   h->pend = 0;
   return MUSED_OK;
@@ -459,6 +486,10 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   ZALLOC(h->queue, 8 * S * cap * dd);
   ZALLOC(h->qt, 8 * S * cap);
   ZALLOC(h->meta, 4 * S * 4);
+  {
+    const char* dd = getenv("MUSED_SWFD_DEDUPE");
+    if (!(dd && dd[0] == '0')) ALLOC(h->rep, 4 * S);
+  }
   ZALLOC(h->dropped, 8 * S);
   ALLOC(h->theta, 8 * S);
   ALLOC(h->T, 8 * S * l * dd); ALLOC(h->Wc, 8 * S * l * n2); ALLOC(h->evals, 8 * S * n2); ALLOC(h->U, 8 * S * n2 * n2);
@@ -476,7 +507,7 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   MUSED_CHECK_HIP(hipMemcpy(h->theta, th.data(), 8 * S, hipMemcpyHostToDevice));
   int rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
-  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig))) return rc;
+  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep))) return rc;
   if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq))) return rc;
   *out = h;
   return MUSED_OK;
@@ -488,7 +519,8 @@ int mused_swfd_destroy(void* handle) {
   eig_plan_destroy(h->eig);
   eig_plan_destroy(h->eigq);
   void* bufs[] = {h->buf, h->queue, h->qt, h->meta, h->dropped, h->theta, h->T, h->Wc, h->evals, h->U, h->plan,
-                  h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel};
+                  h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel,
+                  h->rep};
   for (void* b : bufs) (void)hipFree(b);
   delete h;
   return MUSED_OK;
@@ -538,6 +570,16 @@ int mused_swfd_append_lanes(void* handle, const void* rows, int dtype, long n_ro
 }
 
 int mused_swfd_lanes(void* handle) { return handle ? ((Swfd*)handle)->lanes : -1; }
+
+// Diagnostic (not part of the declared ABI): copies rep[S] and meta[S][4] of the last rotation to host arrays.
+int mused_swfd_debug_state(void* handle, int* rep_out, int* meta_out) {
+  Swfd* h = (Swfd*)handle;
+  if (!h) return MUSED_ERR_ARG;
+  MUSED_CHECK_HIP(hipDeviceSynchronize());
+  if (h->rep && rep_out) MUSED_CHECK_HIP(hipMemcpy(rep_out, h->rep, 4 * (size_t)h->S, hipMemcpyDeviceToHost));
+  if (meta_out) MUSED_CHECK_HIP(hipMemcpy(meta_out, h->meta, 16 * (size_t)h->S, hipMemcpyDeviceToHost));
+  return h->rep ? 1 : 0;
+}
 
 // Replaces SeqBasedSWFD.get() (main.py:70): out_sketch (l x d fp64), out_sigma (l, row norms of the
 // sketch = its singular values), out_info = {level used, delta of the final shrink}.  Device pointers.
