@@ -324,3 +324,30 @@ def test_rank_deficient_buffers(d):
         ora.fit(X[lo:hi])
         _compare(dev, ora, f"d={d} t={hi}")
     dev.close()
+
+
+def test_duplicate_levels_solved_once_changes_nothing(monkeypatch):
+    """Sketch levels that are still bit-identical are solved once (mused_swfd: representative map); switching that
+    off must give the same sketch, snapshot rings and exported state bit for bit."""
+    from mused_amd import synth
+    from mused_amd.swfd import SeqBasedSWFD as Dev
+
+    N, ell, d = 600, 16, 64
+    X, _ = synth.make_stream("blob", 3 * N + 77, d, 5)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MUSED_SWFD_DEDUPE", flag)
+        sk = Dev(N=N, R=R, d=d, sketch_dim=ell)
+        res = []
+        for lo, hi in [(0, 250), (250, 1300), (1300, 3 * N + 77)]:
+            sk.fit(X[lo:hi])
+            B, s, lvl, dl = sk.get()
+            res.append((B.copy(), s.copy(), lvl, dl))
+        res.append(sk.export_half(1).cpu().numpy().copy())
+        res.append(sk.export_half(0).cpu().numpy().copy())
+        sk.close()
+        outs.append(res)
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
