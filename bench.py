@@ -16,7 +16,7 @@ lanes on two HIP streams, while a third, high-priority stream runs adjacency -> 
 pool of host workers the k-means / matching.  `roofline` is the Jacobi round kernel as it runs in the timed region (per
 launch, next to the other group's launches), `roofline_isolated` the same kernel with the GPU to itself.
 
-    python bench.py                       # 1 GPU, K = 9, W = 1
+    python bench.py                       # 1 GPU, K = 10, W = 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -47,14 +47,14 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blob", choices=["blob", "gauss", "fd"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
-    ap.add_argument("--lanes", type=int, default=9,
+    ap.add_argument("--lanes", type=int, default=10,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
                          "launches (1 = strictly one window at a time)")
     ap.add_argument("--sketch-groups", type=int, default=0,
