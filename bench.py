@@ -361,6 +361,11 @@ def main():
         ev_pairs = pipe.eng.score_events
         pipe.eng.score_events = None
         gemm_live_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None
+        # the live Jacobi timing covers the timed region only: read it before the stand-alone stage runs below
+        osj_reads = []
+        for sk in sketches:
+            osj_reads.append(sk.profile_read())
+            sk.profile(False)
         stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all[grp[0][0]:grp[0][1]] if grp else rows_all)
         stages["swfd_groups"] = [b - a for a, b in grp]
         stages["scores_gemm_ms_live_timed_region"] = gemm_live_ms
@@ -376,9 +381,7 @@ def main():
             # per-launch rate is about 1 / G of what the kernel sustains across the streams (`achieved_all_streams`).
             osj_ms = osj_launches = 0
             osj_total_bytes = 0.0
-            for sk in sketches:
-                ms_g, n_g, b_g = sk.profile_read()
-                sk.profile(False)
+            for ms_g, n_g, b_g in osj_reads:
                 osj_ms += ms_g
                 osj_launches += n_g
                 osj_total_bytes += n_g * b_g
