@@ -29,6 +29,7 @@ struct Swfd {
   long i;    // rows seen so far
   int pend;  // rows appended since the last rotation (they sit raw in every buffer)
   long restart_mark;  // value of i for which the epoch-start swap has already been done
+  bool twin;  // MAIN and AUX of every level still identical (both empty at the start of this epoch, no state imported)
   int sweeps;
   // persistent state
   double* buf;         // S x n2 x d
@@ -99,10 +100,20 @@ __global__ void swfd_set_now_kernel(long long* now, long long v) { *now = v; }
 // rotate product; the others read the representative's and apply their own threshold (results unchanged: identical
 // inputs through the same deterministic kernels).  On the 8-blob stream of the benchmark 3 of 28 sketches are
 // duplicates in steady state, 17 of 28 in the first window of a stream.  One thread per (lane, kind).
-__global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains, int* __restrict__ rep) {
+__global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains, int* __restrict__ rep, int twin) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nchains) return;
-  const int base = c * L;  // sketch index = lane * 2L + kind * L + level = chain * L + level
+  // first epoch of a stream: AUX is the twin of MAIN (both started empty) -> the AUX chain maps onto the MAIN chain
+  const int base = ((twin && (c & 1)) ? c - 1 : c) * L;  // sketch index = lane * 2L + kind * L + level = chain * L + level
+  if (twin && (c & 1)) {
+    int r = base + L - 1;
+    rep[c * L + L - 1] = r;
+    for (int j = L - 2; j >= 0; --j) {
+      if (meta[(base + j) * 4 + 3] != 0) r = base + j;
+      rep[c * L + j] = r;
+    }
+    return;
+  }
   int r = base + L - 1;
   rep[r] = r;
   for (int j = L - 2; j >= 0; --j) {
@@ -229,7 +240,8 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
   int rc;
   hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
   if (h->rep)
-    hipLaunchKernelGGL(swfd_rep_kernel, dim3(cdiv(2 * h->lanes, 64)), dim3(64), 0, st, h->meta, h->L, 2 * h->lanes, h->rep);
+    hipLaunchKernelGGL(swfd_rep_kernel, dim3(cdiv(2 * h->lanes, 64)), dim3(64), 0, st, h->meta, h->L, 2 * h->lanes, h->rep,
+                       h->twin ? 1 : 0);
   if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
                      (long)n2 * n2, n2, n2, d, S, 1.0, st, h->rep)))
     return rc;
@@ -268,6 +280,7 @@ static int swfd_append_t(Swfd* h, const T* X, long ldx, long lane_stride, long m
       // first row of a new epoch (pend == 0 here: the epoch-end rotation has run)
       if ((rc = swfd_restart(h, st))) return rc;
       h->restart_mark = h->i;
+      h->twin = false;  // MAIN now carries the previous epoch, AUX starts empty
     }
     const long in_epoch = h->i % h->N;
     long until = h->ell - (in_epoch % h->ell);
@@ -479,6 +492,7 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   // matrices (d < 2l, or linearly dependent rows) need up to 20 to push the null-space columns below the drop tolerance
   h->sweeps = sweeps > 0 ? sweeps : 24;
   h->restart_mark = -1;
+  h->twin = true;  // both halves empty
   const size_t S = h->S, n2 = h->n2, n4 = h->n4, cap = h->cap, dd = d, l = ell;
 #define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))
 #define ZALLOC(p, bytes) do { ALLOC(p, bytes); MUSED_CHECK_HIP(hipMemset((p), 0, (bytes))); } while (0)
@@ -633,6 +647,7 @@ int mused_swfd_import_half(void* handle, int kind, const void* src, void* stream
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && src && (kind == 0 || kind == 1), "mused_swfd_import_half: bad arguments");
   MUSED_REQUIRE(h->lanes == 1, "mused_swfd_import_half: single-lane handles only");
+  h->twin = false;
   return half_copy(h, kind, (char*)src, false, (hipStream_t)stream);
 }
 
@@ -657,6 +672,7 @@ int mused_swfd_begin_epoch(void* handle, long rows_seen, const void* main_half, 
   h->i = rows_seen;
   h->pend = 0;
   h->restart_mark = rows_seen;  // the epoch-start swap is what this call just did
+  h->twin = (main_half == nullptr);
   return MUSED_OK;
 }
 
