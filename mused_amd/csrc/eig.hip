@@ -989,7 +989,7 @@ static int enqueue_sweeps(EigPlan* p, hipStream_t st) {
   return cur;
 }
 
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep) {
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep, int flags) {
   MUSED_REQUIRE(n >= 2 && n % 2 == 0 && batch >= 1 && sweeps >= 1, "eig_plan_create: n must be even (n=%d)", n);
   EigPlan* p = new EigPlan();
   memset(p, 0, sizeof(*p));
@@ -1004,20 +1004,21 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
     MUSED_CHECK_HIP(hipMalloc(&p->G[0], bytes));
     MUSED_CHECK_HIP(hipMalloc(&p->Gc, sizeof(double) * (size_t)batch * p->ldn * p->ldn));
     MUSED_CHECK_HIP(hipMalloc(&p->lam, sizeof(double) * (size_t)batch * p->ldn));
-    // Adaptive sweep count (off by default): the all-pairs criterion also waits for the smallest
-    // eigen-directions, which the path never uses, and costs more sweeps than the fixed count that is
-    // enough for the upper half of the spectrum.  MUSED_EIG_ADAPTIVE=1 turns it on.
     const char* sf = getenv("MUSED_OSJ_SORT_FROM");
     p->sort_from = sf ? atoi(sf) : 0;
     const char* wk = getenv("MUSED_OSJ_WAVE");  // 0: row-per-thread kernel for every order
     p->wavek = (p->ldn <= 512 && !(wk && wk[0] == '0')) ? 1 : 0;
     const char* so = getenv("MUSED_OSJ_SORT");
     p->sortcols = (so && so[0] == '0') ? 0 : 1;  // row-per-thread kernel only: helps on rank-deficient matrices
+    if (flags & EIG_PLAN_NO_SORT) {  // columns stay where they are (the caller reads parts of them by position)
+      p->sort_from = 1 << 30;
+      p->sortcols = 0;
+    }
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
     // stops after the first sweep that met no column pair with cos^2 above the threshold (osj_pair_active).  How many sweeps
     // that takes depends on the matrix (full-rank sketch buffers ~10 at order 256, rank-deficient ones up to 16).
     const char* ad = getenv("MUSED_EIG_ADAPTIVE");
-    if (!(ad && ad[0] == '0')) {
+    if (!(ad && ad[0] == '0') && !(flags & EIG_PLAN_FIXED_SWEEPS)) {
       // [trace (batch doubles) | work counter (1 x u64) | flags (batch * sweeps ints)]
       MUSED_CHECK_HIP(hipMalloc(&p->trace, sizeof(double) * ((size_t)batch + 1) + sizeof(int) * (size_t)batch * sweeps));
       p->work = (unsigned long long*)(p->trace + batch);
@@ -1043,6 +1044,10 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
     }
     MUSED_CHECK_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
     p->have_graph = true;
+    // the capture stream has done its job: every live HIP stream competes for the few hardware queues the user's
+    // streams are mapped onto (two sketch groups + the main path need three of them undisturbed)
+    (void)hipStreamDestroy(p->cap_stream);
+    p->cap_stream = nullptr;
   }
   *out = p;
   return MUSED_OK;
@@ -1053,7 +1058,7 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->have_graph) {
     (void)hipGraphExecDestroy(p->exec);
     (void)hipGraphDestroy(p->graph);
-    (void)hipStreamDestroy(p->cap_stream);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   }
   for (int i = 0; i < 2; ++i) {
     if (p->G[i]) (void)hipFree(p->G[i]);

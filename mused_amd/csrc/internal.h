@@ -40,7 +40,9 @@ int adj_transpose(const unsigned long long* mask, int n, int words, unsigned lon
 struct EigPlan;
 // own_graph: capture the sweep launches into a private hipGraph (set false when the caller
 // captures a larger pipeline that contains this solve).
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr);
+constexpr int EIG_PLAN_FIXED_SWEEPS = 1;  // always `sweeps` sweeps (no convergence flags)
+constexpr int EIG_PLAN_NO_SORT = 2;       // no column sorting: column j of the result descends from column j of the input
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr, int flags = 0);
 // rep (device, batch ints, optional, read at every solve): matrix b is solved only when rep[b] == b
 void eig_plan_destroy(EigPlan* p);
 // In: G (batch x n x n, symmetric) is copied into the plan's workspace.  Out: eigenvalues
