@@ -11,12 +11,12 @@ One STEP = one window of W rows, already resident in HBM, through the whole path
 `value` = rows of all ranks / wall time of the K timed steps (max over ranks), inputs resident.
 
 In-GPU concurrency (one rank): the K windows are dealt to B "lanes" (contiguous blocks of the stream, each preceded by
-its warm-up = halo window); the sketches of the lanes advance in lockstep inside shared launches, in TWO groups of
-lanes on two HIP streams, while a third, high-priority stream runs adjacency -> eigenstep of the same windows and a
+its warm-up = halo window); the sketches of the lanes advance in lockstep inside shared launches, in THREE groups of
+lanes on three HIP streams, while a fourth, high-priority stream runs adjacency -> eigenstep of the same windows and a
 pool of host workers the k-means / matching.  `roofline` is the Jacobi round kernel as it runs in the timed region (per
 launch, next to the other group's launches), `roofline_isolated` the same kernel with the GPU to itself.
 
-    python bench.py                       # 1 GPU, K = 10, W = 1
+    python bench.py                       # 1 GPU, K = 9, W = 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -47,21 +47,21 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blob", choices=["blob", "gauss", "fd"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
-    ap.add_argument("--lanes", type=int, default=10,
+    ap.add_argument("--lanes", type=int, default=9,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
                          "launches (1 = strictly one window at a time)")
     ap.add_argument("--sketch-groups", type=int, default=0,
-                    help="independent groups of lanes, each on its own HIP stream / host thread (0 = auto: 2 groups "
-                         "from 4 lanes): their launches interleave on the GPU, so the Gram / rotate GEMMs of one group "
-                         "overlap the Jacobi rounds of the other and partly filled workgroup rounds are shared.  More "
-                         "than 2 groups + the main stream exceed the hardware queues HIP hands out and serialise.")
+                    help="independent groups of lanes, each on its own HIP stream / host thread (0 = auto: 3 groups "
+                         "from 6 lanes, 2 from 4): their launches interleave on the GPU, so the Gram / rotate GEMMs of one "
+                         "group overlap the Jacobi rounds of the others and partly filled workgroup rounds are shared.  More "
+                         "than 3 groups + the main stream exceed the hardware queues HIP hands out and serialise.")
     return ap.parse_args()
 
 
@@ -249,7 +249,7 @@ def main():
         # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
         R0 = float((rows_all[0, 0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
         R = mdist.broadcast_scalar(R0, 0, device=coll_dev) if world > 1 else R0
-        G = args.sketch_groups if args.sketch_groups > 0 else (2 if B >= 4 else 1)
+        G = args.sketch_groups if args.sketch_groups > 0 else (3 if B >= 6 else (2 if B >= 4 else 1))
         G = max(1, min(G, B))
         l0 = 0
         for g in range(G):
