@@ -221,7 +221,6 @@ int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out
   if ((rc = gemm_f64_prepare_all())) return rc;
   const char* ng = getenv("MUSED_NO_GRAPH");
   h->use_graph = !(ng && ng[0] == '1');
-  if (h->use_graph) MUSED_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
   *out = h;
   return MUSED_OK;
 }
@@ -272,9 +271,13 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
   if (h->use_graph) {
     if (!h->have_graph || h->g_n != n || h->g_r != r || h->g_ncomp != n_comp || h->g_iter != n_iter) {
       rsvd_drop_graph(h);
+      // the capture stream lives only while it records: every live HIP stream competes for the hardware queues
+      if (!h->cap_stream) MUSED_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
       MUSED_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
       rc = rsvd_enqueue(h, n, r, n_comp, n_iter, h->cap_stream);
       hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
+      (void)hipStreamDestroy(h->cap_stream);
+      h->cap_stream = nullptr;
       if (rc || e != hipSuccess) {
         if (!rc) set_error("mused_rsvd_reduce: graph capture failed (%s)", hipGetErrorString(e));
         return rc ? rc : MUSED_ERR_HIP;
