@@ -29,6 +29,12 @@ import os
 import sys
 import time
 
+# HIP maps streams onto a few hardware queues (4 by default) and streams that share one run in order.  This script
+# keeps 4 streams busy per rank (3 sketch groups + the main path) next to the default stream and whatever the
+# collective library opens: with 8 queues the result no longer depends on how many other streams exist (with 4, two idle
+# extra streams cost a third of the throughput).  Must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -263,6 +269,11 @@ def main():
     # the adjacency / eigenstep stream gets the HIGH priority: a chain of ~3600 small dependent launches per window,
     # each of which would otherwise queue behind a full wave of sketch workgroups
     hi_main = os.environ.get('MUSED_BENCH_PRIO', 'main') == 'main'
+    # (diagnostic: idle extra streams, to see how robust the stream -> hardware-queue mapping is)
+    _extra = [torch.cuda.Stream() for _ in range(int(os.environ.get('MUSED_BENCH_EXTRA_STREAMS', '0')))]
+    for _e in _extra:
+        with torch.cuda.stream(_e):
+            torch.zeros(1, device='cuda')
     st_main = torch.cuda.Stream(priority=-1 if hi_main else 0)
     st_sketch = [torch.cuda.Stream(priority=0 if hi_main else -1) for _ in sketches]
     pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=False, async_labels=True, stream=st_main)
