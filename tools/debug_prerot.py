@@ -17,6 +17,8 @@ def prerot(X):
                 r1 = min(r0 + ell, (e + 1) * W)
                 P = X[b, r0:r1]
                 lam, Q = torch.linalg.eigh(P @ P.T)
+                if os.environ.get('TORCH_PREROT') == 'desc':
+                    Q = Q.flip(1)
                 Y[b, r0:r1] = Q.T @ P
     return Y
 def run(X, tag):
