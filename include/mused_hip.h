@@ -91,6 +91,9 @@ int mused_rsvd_set_q0(void* handle, const double* Q0, int n, int r, void* stream
  * may be NULL) = Vt.T after svd_flip. */
 int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double* out_embed, double* out_sigma,
                       double* out_components, void* stream);
+/* device int[4] raised by mused_rsvd_reduce (flags[0] != 0: more than nnz_cap edges -> lists truncated, result
+ * invalid but memory-safe); copy it on the same stream behind the call for a sync-free check */
+const int* mused_rsvd_flags(void* handle);
 /* BLOCKING: flags_out[0] != 0 -> more than nnz_cap edges; stats_out = {max out-deg, nnz, max in-deg, nnz} (HOST) */
 int mused_rsvd_status(void* handle, int* flags_out, int* stats_out, void* stream);
 

@@ -43,6 +43,7 @@ _PROTOS = {
     "mused_rsvd_mask_buffer": (_vp, [_vp]),
     "mused_rsvd_set_q0": (_i, [_vp, _vp, _i, _i, _vp]),
     "mused_rsvd_reduce": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mused_rsvd_flags": (_vp, [_vp]),
     "mused_rsvd_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), _vp]),
     "mused_spmm_binary": (_i, [_vp, _vp, _i, _vp, _l, _i, _vp, _l, _vp]),
     "mused_lu_permute_l": (_i, [_vp, _i, _i, _l, _vp, _vp, _vp]),

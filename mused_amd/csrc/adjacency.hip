@@ -40,9 +40,13 @@ __global__ void mask_degree_kernel(const unsigned long long* __restrict__ mask, 
   if (lane == 0) deg[row] = c;
 }
 
-// single workgroup: rowptr = exclusive scan(deg), stats[0] = max degree, stats[1] = nnz
+// single workgroup: rowptr = exclusive scan(deg), stats[0] = max degree, stats[1] = nnz.
+// cap > 0: every rowptr entry is clamped to cap (the capacity of the colidx array the lists go to) and *overflow
+// is raised when nnz > cap, so that a consumer walking rowptr[i] .. rowptr[i+1] never leaves colidx -- the lists
+// are then truncated (results invalid, flagged), never out of bounds.
 __global__ __launch_bounds__(1024) void degree_scan_kernel(const int* __restrict__ deg, int n, int* __restrict__ rowptr,
-                                                          int* __restrict__ stats) {
+                                                          int* __restrict__ stats, long cap = 0,
+                                                          int* __restrict__ overflow = nullptr) {
   __shared__ int wsum[16];
   __shared__ int carry;
   __shared__ int smax;
@@ -70,15 +74,19 @@ __global__ __launch_bounds__(1024) void degree_scan_kernel(const int* __restrict
       b += (j < w) ? c : 0;
       tot += c;
     }
-    if (i < n) rowptr[i] = b + x - v;
+    if (i < n) {
+      const int rp = b + x - v;
+      rowptr[i] = (cap > 0 && rp > cap) ? (int)cap : rp;
+    }
     __syncthreads();
     if (threadIdx.x == 0) carry += tot;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    rowptr[n] = carry;
+    rowptr[n] = (cap > 0 && carry > cap) ? (int)cap : carry;
     stats[0] = smax;
     stats[1] = carry;
+    if (cap > 0 && carry > cap && overflow) atomicOr(overflow, 1);
   }
 }
 
@@ -183,7 +191,7 @@ int zero_ints(int* p, long n, hipStream_t st) {
 int adj_csr_from_mask(const unsigned long long* mask, int n, int words, int* deg, int* rowptr, int* colidx,
                       int* stats, long cap, int* overflow, hipStream_t st) {
   hipLaunchKernelGGL(mask_degree_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, mask, n, words, deg);
-  hipLaunchKernelGGL(degree_scan_kernel, dim3(1), dim3(1024), 0, st, deg, n, rowptr, stats);
+  hipLaunchKernelGGL(degree_scan_kernel, dim3(1), dim3(1024), 0, st, deg, n, rowptr, stats, cap, overflow);
   hipLaunchKernelGGL(mask_to_csr_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, mask, n, words, rowptr, colidx, cap,
                      overflow);
   MUSED_LAUNCH_CHECK();
@@ -231,7 +239,7 @@ int mused_adj_degrees(const unsigned long long* mask, int n, int words, int* deg
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(mask_degree_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, mask, n, words, deg);
   MUSED_LAUNCH_CHECK();
-  hipLaunchKernelGGL(degree_scan_kernel, dim3(1), dim3(1024), 0, st, deg, n, rowptr, stats);
+  hipLaunchKernelGGL(degree_scan_kernel, dim3(1), dim3(1024), 0, st, deg, n, rowptr, stats, 0l, (int*)nullptr);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }

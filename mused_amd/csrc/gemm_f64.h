@@ -17,6 +17,7 @@
 // One f64 MFMA is 64 cycles per SIMD, 16 of them per 8 ds_read_b64: the loop is
 // matrix-pipe bound by construction.
 #pragma once
+#include <mutex>
 #include "common.h"
 
 namespace mused {
@@ -312,14 +313,16 @@ struct EpiStore {
 
 template <typename TA, typename TB, bool A_KC, bool B_KC, bool VEC, typename Epi>
 int gemm_f64_prepare_t() {
-  // > 64 KiB of dynamic LDS needs the attribute once per kernel; done outside stream capture.
-  static bool done = false;
-  if (!done) {
+  // > 64 KiB of dynamic LDS needs the attribute once per kernel; done outside stream capture.  Several host
+  // threads drive the library (sketch groups + the main path): one-time, thread-safe.
+  static std::once_flag once;
+  static hipError_t err = hipSuccess;
+  std::call_once(once, [] {
     auto k = gemm_f64_kernel<TA, TB, A_KC, B_KC, VEC, Epi>;
-    MUSED_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    done = true;
-  }
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              GEMM_LDS_BYTES);
+  });
+  MUSED_CHECK_HIP(err);
   return MUSED_OK;
 }
 

@@ -85,8 +85,11 @@ static int scores_launch(const T* X, long n, int d, long ld, int metric, double*
   memset(&g, 0, sizeof(g));
   g.A = X; g.B = X; g.lda = ld; g.ldb = ld; g.M = (int)n; g.N = (int)n; g.K = d;
   // X X^T: the squared-distance / cosine epilogues are symmetric in (row, col) -> upper tiles only, mirrored stores
-  const char* sy = getenv("MUSED_SCORES_SYM");
-  g.sym = (sy && sy[0] == '0') ? 0 : 1;
+  static const int sym = [] {
+    const char* sy = getenv("MUSED_SCORES_SYM");
+    return (sy && sy[0] == '0') ? 0 : 1;
+  }();
+  g.sym = sym;
   const bool vec = vec_ok<T>(X, ld, 0);
   if (metric == 0) {
     EpiSqL2 epi{S, n, norms};

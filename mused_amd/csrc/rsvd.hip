@@ -120,11 +120,12 @@ __global__ void col_scale_kernel(double* __restrict__ V, long total, int ncol, c
   if (gid < total) V[gid] *= signs[gid % ncol];
 }
 
-static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream_t st) {
+static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream_t st, bool capturing) {
   const int words = (n + 63) / 64;
   const long ld = r;
   int rc_;
-  static const bool dbg = getenv("MUSED_DEBUG") != nullptr;
+  static const bool dbg_env = getenv("MUSED_DEBUG") != nullptr;
+  const bool dbg = dbg_env && !capturing;  // a stream that is being captured must not be synchronised
   int stage = 0;
 #define RC(x)                                                                                     \
   do {                                                                                            \
@@ -274,7 +275,7 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
       // the capture stream lives only while it records: every live HIP stream competes for the hardware queues
       if (!h->cap_stream) MUSED_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
       MUSED_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-      rc = rsvd_enqueue(h, n, r, n_comp, n_iter, h->cap_stream);
+      rc = rsvd_enqueue(h, n, r, n_comp, n_iter, h->cap_stream, true);
       hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
       (void)hipStreamDestroy(h->cap_stream);
       h->cap_stream = nullptr;
@@ -288,7 +289,7 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
     }
     MUSED_CHECK_HIP(hipGraphLaunch(h->exec, st));
   } else {
-    if ((rc = rsvd_enqueue(h, n, r, n_comp, n_iter, st))) return rc;
+    if ((rc = rsvd_enqueue(h, n, r, n_comp, n_iter, st, false))) return rc;
   }
   MUSED_CHECK_HIP(hipMemcpyAsync(out_embed, h->embed, sizeof(double) * (size_t)n * n_comp, hipMemcpyDeviceToDevice, st));
   MUSED_CHECK_HIP(hipMemcpyAsync(out_sigma, h->sigma, sizeof(double) * (size_t)n_comp, hipMemcpyDeviceToDevice, st));
@@ -297,6 +298,11 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
                                    hipMemcpyDeviceToDevice, st));
   return MUSED_OK;
 }
+
+// Device int[4] the eigenstep raises its flags in (flags[0] != 0: the adjacency had more than nnz_cap edges, the
+// neighbour lists were truncated and the result of that mused_rsvd_reduce is INVALID).  Rewritten by every
+// mused_rsvd_reduce on its stream: copy it behind the call (same stream) to read it without a host sync.
+const int* mused_rsvd_flags(void* handle) { return handle ? ((Rsvd*)handle)->flags : nullptr; }
 
 // Blocking status read: flags[0] != 0 -> the adjacency had more than nnz_cap edges (results invalid);
 // stats = {max out-degree, nnz, max in-degree, nnz}.

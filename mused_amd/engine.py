@@ -206,9 +206,13 @@ class WindowEngine:
         return self._rsvd
 
     def svd_reduce(self, adj: Adjacency, reduced_dim: int, seed: int, n_iter: int = 5, n_oversamples: int = 10,
-                   nnz_cap: int | None = None, want_components: bool = False):
+                   nnz_cap: int | None = None, want_components: bool = False, want_flags: bool = False):
         """perform_svd_reduction on a device adjacency: (embedding (n, n_comp), sigma (n_comp,)) fp64
-        device tensors.  Q0 is generated on the host exactly as sklearn does and cached per (n, r, seed)."""
+        device tensors.  Q0 is generated on the host exactly as sklearn does and cached per (n, r, seed).
+        `nnz_cap` is a caller-supplied bound on the number of edges (no host sync); if the adjacency has more, the
+        neighbour lists are truncated on the device (memory-safe) and flags[0] is raised: with `want_flags` a copy
+        of the int32[4] flag word (taken on the same stream) is appended to the result for the caller to check once
+        the stream has run -- `check_rsvd_flags`."""
         n = adj.n
         n_comp = min(int(reduced_dim), n - 1)
         if n_comp < 1:
@@ -231,7 +235,21 @@ class WindowEngine:
         comp = torch.empty((n, n_comp), dtype=torch.float64, device=self.device) if want_components else None
         call("mused_rsvd_reduce", h, n, n_comp, r, n_iter, ptr(emb), ptr(sig), ptr(comp) if want_components else None,
              stream_ptr())
-        return (emb, sig, comp) if want_components else (emb, sig)
+        out = (emb, sig, comp) if want_components else (emb, sig)
+        if want_flags:
+            flags = torch.empty(4, dtype=torch.int32, device=self.device)
+            _hip_memcpy_d2d(flags.data_ptr(), _lib.lib().mused_rsvd_flags(h), 16)
+            out = out + (flags,)
+        return out
+
+    @staticmethod
+    def check_rsvd_flags(flags) -> None:
+        """Raise if the int32[4] flag word of an eigenstep (host copy) reports truncated neighbour lists."""
+        if int(flags[0]) != 0:
+            raise MusedError(
+                "randomized-SVD eigenstep: the fused adjacency has more edges than the nnz_cap it was given; "
+                "its neighbour lists were truncated and the embedding is invalid"
+            )
 
     def rsvd_status(self):
         flags, stats = (C.c_int * 1)(), (C.c_int * 4)()

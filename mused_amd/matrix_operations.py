@@ -19,9 +19,11 @@ Two call styles:
                              (`adjacency_on_device`, `fuse_matrices` on Adjacency objects,
                              `svd_reduce_on_device`) and nothing W x W ever visits the host.
 
-Not on the device path: the metadata modality types of the SED2012
-dataset ("location", "time", "username", "tags", "text" on raw strings).  They raise
-NotImplementedError here; vectorised text rows can use modality_type="cosine".
+modality_type "text" (matrix_operations.py:91-110) vectorises the ('title', 'description') strings on the
+host with the same scikit-learn TfidfVectorizer call as the reference and runs the cosine / top-(k+1)
+kernel on the device; already vectorised rows can use modality_type="cosine".
+Not on the device path: the other metadata modality types of the SED2012
+dataset ("location", "time", "username", "tags"): they raise NotImplementedError here.
 """
 from __future__ import annotations
 
@@ -29,7 +31,7 @@ import numpy as np
 
 from . import engine as _eng
 
-_METADATA_TYPES = ("location", "time", "username", "tags", "text")
+_METADATA_TYPES = ("location", "time", "username", "tags")
 
 
 def _metric_for(modality_type) -> str:
@@ -39,7 +41,7 @@ def _metric_for(modality_type) -> str:
             "records, matrix_operations.py:22-110) and is outside the device hot path; dense feature "
             'rows use the default type (Euclidean kNN) or "cosine"'
         )
-    return "cosine" if modality_type == "cosine" else "l2"
+    return "cosine" if modality_type in ("cosine", "text") else "l2"
 
 
 def adjacency_on_device(data, modality_type="", k_basis=50, engine=None) -> _eng.Adjacency:
@@ -49,6 +51,8 @@ def adjacency_on_device(data, modality_type="", k_basis=50, engine=None) -> _eng
     (matrix_operations.py:114-115, 126-127)."""
     import torch
 
+    if modality_type == "text":
+        return _text_adjacency(data, k_basis, engine)
     metric = _metric_for(modality_type)
     if isinstance(data, torch.Tensor):
         X = _eng.to_device_rows(data)
@@ -75,12 +79,41 @@ def adjacency_on_device(data, modality_type="", k_basis=50, engine=None) -> _eng
     if X.shape[0] == 0:
         w = _eng.words_for(n)
         return _eng.Adjacency(torch.zeros((n, w), dtype=torch.int64, device=eng.device), n)
-    sub = eng.knn_adjacency(X, k_basis, metric)
-    # scatter the valid-subset adjacency back to window coordinates (rare path: dense round trip)
-    dense = torch.zeros((n, n), dtype=torch.float64, device=X.device)
-    sd = sub.to_dense(torch.float64)
-    dense[valid_idx.unsqueeze(1), valid_idx.unsqueeze(0)] = sd
+    return _scatter_valid(eng.knn_adjacency(X, k_basis, metric), valid_idx, n)
+
+
+def _scatter_valid(sub: _eng.Adjacency, valid_idx, n: int) -> _eng.Adjacency:
+    """Adjacency among the valid rows -> window coordinates (rare path: dense round trip on the device)."""
+    import torch
+
+    dense = torch.zeros((n, n), dtype=torch.float64, device=sub.mask.device)
+    dense[valid_idx.unsqueeze(1), valid_idx.unsqueeze(0)] = sub.to_dense(torch.float64)
     return _eng.Adjacency.from_dense(dense)
+
+
+def _text_adjacency(data, k_basis, engine=None) -> _eng.Adjacency:
+    """matrix_operations.py:91-110: rows with a non-empty title or description are valid; TF-IDF of
+    "title description" on the host (same TfidfVectorizer call), then cosine similarity and the k_basis + 1 most
+    similar rows per row on the device (`MUSED_METRIC_COSINE`)."""
+    import torch
+    from sklearn.feature_extraction.text import TfidfVectorizer
+
+    data = np.asarray(data)
+    n = len(data)
+    eng = engine or _eng.default_engine(max(n, 1))
+    empty = lambda: _eng.Adjacency(torch.zeros((n, _eng.words_for(n)), dtype=torch.int64, device=eng.device), n)
+    valid = np.where(np.any(data != "", axis=1))[0]
+    vd = data[valid]
+    if len(vd) == 0:
+        return empty()
+    text = np.where(vd[:, 0] != "", vd[:, 0], " ") + " " + np.where(vd[:, 1] != "", vd[:, 1], " ")
+    if not np.any(text != " "):
+        return empty()
+    V = np.asarray(TfidfVectorizer().fit_transform(text).todense(), dtype=np.float64)
+    sub = eng.knn_adjacency(_eng.to_device_rows(V), k_basis, "cosine")
+    if len(valid) == n:
+        return sub
+    return _scatter_valid(sub, torch.from_numpy(valid).to(eng.device), n)
 
 
 def create_adjacency_matrix(data, modality_type, k_basis=50):

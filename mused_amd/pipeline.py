@@ -31,12 +31,18 @@ from .swfd import SeqBasedSWFD
 
 class StreamPipeline:
     def __init__(self, window_size, reduced_dim, k_basis, seed, approach="sSVDMC", modality_types=None,
-                 step_window_ratio=1, engine=None, async_labels=True, feature_sketch=False, stream=None):
+                 step_window_ratio=1, engine=None, async_labels=True, feature_sketch=False, stream=None,
+                 assume_finite=False):
         if approach not in ("sSVDMC", "sSVDMC_hung", "SWFDMC"):
             raise ValueError(f"approach {approach!r} is not on the device hot path")
         self.W, self.ell, self.k, self.seed = int(window_size), int(reduced_dim), int(k_basis), int(seed)
         self.approach = approach
         self.types = modality_types
+        # rows with a non-finite entry are dropped from the kNN (matrix_operations.py:114-115).  Finding out needs one
+        # small host read per window (on a side stream, so it does not wait for the previous window's device work);
+        # `assume_finite=True` skips it for callers that generate their rows (the benchmark's synthetic stream)
+        self.assume_finite = bool(assume_finite)
+        self._chk = None
         self.ratio = step_window_ratio
         self.eng = engine or WindowEngine(self.W)
         self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)
@@ -82,6 +88,7 @@ class StreamPipeline:
         # pinned staging buffers are recycled: allocating pinned memory synchronises the device, which
         # would serialise concurrent pipelines
         self._pins = []
+        self._flag_pins = []
         self._device = torch.cuda.current_device()  # worker threads must select it themselves
 
     # ---- device side of one window --------------------------------------------------------------
@@ -89,7 +96,7 @@ class StreamPipeline:
         """mods: list of (W, d_m) float32/float64 tensors on the device.  Returns (reduced (W, m) CUDA
         tensor, sigma CUDA tensor)."""
         types = self.types or [""] * len(mods)
-        adjs = [self.eng.knn_adjacency(m, self.k, mo._metric_for(t)) for m, t in zip(mods, types)]
+        adjs = [self._adjacency(m, t) for m, t in zip(mods, types)]
         fused = self.eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
         if len(adjs) == 1:
             fused.fused = False
@@ -115,19 +122,41 @@ class StreamPipeline:
             self.swfd.fit(fused.to_dense())  # rows of the fused matrix, int64 for >= 2 modalities
             B, sigma, _ = self.swfd.get_device()
             reduced = B.t().contiguous() if B.shape[0] != self.W else B  # main.py:73-76
-            return reduced, sigma
-        nnz_cap = fused.n * max(self.k, 1) * len(adjs)
-        emb, sigma = self.eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap)
-        return emb, sigma
+            return reduced, sigma, None
+        # edges per row: k selected (l2; the row itself is normally one of them) or k + 1 (cosine / text)
+        nnz_cap = fused.n * sum(max(self.k, 1) + (0 if mo._metric_for(t) == "l2" else 1) for t in types)
+        emb, sigma, flags = self.eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap, want_flags=True)
+        return emb, sigma, flags
+
+    def _adjacency(self, m, t):
+        """One modality of one window -> device adjacency, with the reference's row filtering."""
+        if t == "text" or not isinstance(m, torch.Tensor):
+            return mo.adjacency_on_device(m, t, self.k, engine=self.eng)
+        metric = mo._metric_for(t)  # raises for the metadata types that are not on the device path
+        if not self.assume_finite and m.is_floating_point():
+            if self._chk is None:
+                self._chk = torch.cuda.Stream()
+            # the rows of a window are resident before the window is processed (run() uploads the stream first;
+            # process_window's callers hand over resident tensors): the check does not wait for the main stream
+            with torch.cuda.stream(self._chk):
+                ok = bool(torch.isfinite(m).all().item())
+            if not ok:
+                return mo.adjacency_on_device(m, t, self.k, engine=self.eng)
+        return self.eng.knn_adjacency(m, self.k, metric)
 
     # ---- host consumers -------------------------------------------------------------------------
     def _cluster(self, job):
         """Independent per window: wait for the embedding, k-means (main.py:97)."""
-        ev, red_pin, sig_pin, n_clusters, trigger, t_start = job
+        ev, red_pin, sig_pin, n_clusters, trigger, t_start = job[:6]
+        flag_pin = job[6]
         torch.cuda.set_device(self._device)
         ev.synchronize()
         reduced_host, sigma_host = red_pin.numpy().copy(), sig_pin.numpy().copy()
+        flags_host = flag_pin.numpy().copy() if flag_pin is not None else None
         self._pins.append((red_pin, sig_pin))
+        if flag_pin is not None:
+            self._flag_pins.append(flag_pin)
+            WindowEngine.check_rsvd_flags(flags_host)  # raised on the label worker, surfaces in flush()
         t0 = time.perf_counter()
         clusters = mo.perform_clustering(reduced_host, n_clusters, self.seed)
         self.host_ms["kmeans"].append(1e3 * (time.perf_counter() - t0))
@@ -162,15 +191,19 @@ class StreamPipeline:
         t_start = time.perf_counter()
         n_clusters = len(np.unique(true_labels_window))  # main.py:41
         with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream()):
-            reduced, sigma = self.window_device(mods)
+            reduced, sigma, flags = self.window_device(mods)
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
             red_pin, sig_pin = self._get_pins(reduced, sigma)
             red_pin.copy_(reduced, non_blocking=True)
             sig_pin.copy_(sigma, non_blocking=True)
+            flag_pin = None
+            if flags is not None:
+                flag_pin = self._flag_pins.pop() if self._flag_pins else torch.empty(4, dtype=torch.int32, pin_memory=True)
+                flag_pin.copy_(flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start)
+        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin)
         if self._pool is None:
             self._chain(self._cluster(job), job)
         else:
@@ -183,8 +216,15 @@ class StreamPipeline:
     def run(self, data_modalities, true_labels):
         """Stream whole modalities (host or device arrays) through the window loop; returns the
         concatenated event labels (`all_clusters`, main.py:125)."""
-        dev = [m if isinstance(m, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(m)) for m in data_modalities]
-        dev = [m.cuda() for m in dev]
+        dev = []
+        for m in data_modalities:
+            if isinstance(m, torch.Tensor):
+                dev.append(m.cuda())
+                continue
+            a = np.asarray(m)
+            # numeric modalities live on the device; string records ("text") stay on the host for the TF-IDF step
+            dev.append(torch.from_numpy(np.ascontiguousarray(a)).cuda() if a.dtype.kind in "fiub" else a)
+        torch.cuda.current_stream().synchronize()  # rows resident before the first window (see _adjacency)
         n = dev[0].shape[0]
         for i in range(n):
             if i + 1 >= self.W and (i + 1) * self.ratio % self.W == 0:  # main.py:32
@@ -214,8 +254,9 @@ def process_streaming_data(results, data_modalities, modality_types, window_size
     metrics_evaluation (out of scope here); this returns `results` with the label arrays and the
     wall time instead."""
     t0 = time.time_ns()
-    types = [t if t in ("cosine",) else "" for t in modality_types]
-    pipe = StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, types, step_window_ratio)
+    # modality types go through unchanged: "" / anything the reference does not special-case = Euclidean kNN
+    # (matrix_operations.py:112), "text" and "cosine" = the cosine kernel, the other SED2012 metadata types raise
+    pipe = StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, list(modality_types), step_window_ratio)
     clusters = pipe.run(data_modalities, np.asarray(complete_true_labels))
     pipe.close()
     results = dict(results or {})

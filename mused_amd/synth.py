@@ -55,6 +55,31 @@ def two_modality_blob_stream(n: int, d_each: int, seed: int = 0, n_centres: int 
     return mods, labels.astype(np.int64)
 
 
+def text_stream(n: int, seed: int = 0, vocab: int = 120, topics: int = 4, blank_rate: float = 0.04):
+    """Synthetic ('title', 'description') string records for the reference's "text" modality
+    (matrix_operations.py:91-110): every document draws its words from a topic-specific distribution over a small
+    vocabulary (so that any two documents share words: no exact-zero cosine ties), a few rows have a blank title,
+    a blank description, or both (both blank = invalid row, :96).  Returns ((n, 2) array of str, topic labels)."""
+    rng = np.random.default_rng([seed, 0x7E57])
+    words = np.array([f"w{i:03d}" for i in range(vocab)])
+    base = rng.dirichlet(np.full(vocab, 0.6))
+    dist = np.array([0.35 * base + 0.65 * rng.dirichlet(np.full(vocab, 0.08)) for _ in range(topics)])
+    labels = rng.integers(0, topics, size=n)
+    data = np.empty((n, 2), dtype=object)
+    for i in range(n):
+        p = dist[labels[i]]
+        data[i, 0] = " ".join(rng.choice(words, size=int(rng.integers(4, 9)), p=p))
+        data[i, 1] = " ".join(rng.choice(words, size=int(rng.integers(25, 50)), p=p))
+        u = rng.random()
+        if u < blank_rate:
+            data[i, 0] = ""
+        elif u < 2 * blank_rate:
+            data[i, 1] = ""
+        elif u < 2.5 * blank_rate:
+            data[i, 0] = data[i, 1] = ""
+    return data.astype(str), labels.astype(np.int64)
+
+
 STREAMS = {"gauss": gauss_stream, "blob": blob_stream, "fd": fd_stream}
 
 

@@ -108,11 +108,29 @@ def knn_mask(data: np.ndarray, k: int, metric: str = "l2") -> tuple[np.ndarray, 
     return valid, _select_k_smallest_mask(score, kk)
 
 
+def text_vectors(data):
+    """matrix_operations.py:95-105: rows with any non-empty column are valid; title and description are
+    joined with blanks standing in for empty fields and vectorised by scikit-learn's TfidfVectorizer (the same
+    library call as the reference; default parameters).  Returns (valid_indices, dense (n_valid, vocab) float64)."""
+    from sklearn.feature_extraction.text import TfidfVectorizer
+
+    data = np.asarray(data)
+    valid = np.where(np.any(data != "", axis=1))[0]
+    vd = data[valid]
+    if len(vd) == 0:
+        return valid, np.zeros((0, 0))
+    text = np.where(vd[:, 0] != "", vd[:, 0], " ") + " " + np.where(vd[:, 1] != "", vd[:, 1], " ")
+    if not np.any(text != " "):
+        return valid, np.zeros((len(vd), 0))
+    return valid, np.asarray(TfidfVectorizer().fit_transform(text).todense(), dtype=np.float64)
+
+
 def create_adjacency_matrix(data, modality_type, k_basis=50):
     """matrix_operations.py:14-20,112-132 for the dense numeric `case _`
-    (any modality_type the reference does not special-case) and a dense
-    "cosine" type (the cosine kernel of the reference's `text` branch,
-    :101-108, applied to already-vectorised rows).
+    (any modality_type the reference does not special-case), the `text`
+    branch (:91-110: TF-IDF + cosine + top-(k+1)) and a dense "cosine" type
+    (the cosine kernel of that branch, :106-108, applied to already-vectorised
+    rows).
 
     Returns the (n, n) float64 0/1 matrix: A[i, j] = 1 iff j is among the
     selected neighbours of i and j != i (directed; :123-130).
@@ -120,6 +138,13 @@ def create_adjacency_matrix(data, modality_type, k_basis=50):
     data = np.asarray(data)
     n = len(data)
     A = np.zeros((n, n))
+    if modality_type == "text":
+        valid, V = text_vectors(data)
+        if len(valid) and V.shape[1]:
+            mask = _select_k_smallest_mask(cosine_scores(V), min(k_basis + 1, len(valid)))
+            np.fill_diagonal(mask, False)
+            A[np.ix_(valid, valid)] = mask
+        return A
     metric = "cosine" if modality_type == "cosine" else "l2"
     valid, mask = knn_mask(data, k_basis, metric)
     if len(valid):

@@ -54,7 +54,7 @@ def regen_inputs(g):
     n, d, W, ell, k, seed = (int(x) for x in g["meta"])
     kind = str(g["kind"])
     if kind == "blob2":
-        mods, labels = synth.two_modality_blob_stream(n, d, seed, n_centres=4)
+        mods, labels = synth.two_modality_blob_stream(n, d, seed, n_centres=int(g["n_centres"]) if "n_centres" in g.files else 4)
     elif kind == "blob":
         nc = 8 if d >= 256 else 4
         X, labels = synth.blob_stream(n, d, seed, n_centres=nc, sep=2.0)
@@ -65,6 +65,27 @@ def regen_inputs(g):
     digests = [synth.array_digest(m) for m in mods]
     assert digests == [str(x) for x in g["input_digest"]], "regenerated inputs differ from the golden run's"
     return mods, labels, (n, d, W, ell, k, seed)
+
+
+def text_inputs(g):
+    """Regenerate the synthetic string records of tests/golden/cosine.npz and check their digest."""
+    from mused_amd import synth
+
+    n, k, seed = (int(x) for x in g["text_meta"])
+    data, labels = synth.text_stream(n, seed)
+    assert hashlib.sha256("\x1f".join(data.ravel()).encode()).hexdigest() == str(g["text_digest"])
+    return data, labels, n, k
+
+
+COSINE_DENSE_CASES = [("gauss", 500, 64, 0, 10), ("gauss", 500, 64, 0, 50), ("blob", 700, 96, 1, 10), ("blob", 700, 96, 1, 50)]
+
+
+def cosine_dense_inputs(g, tag, n, d, seed, k):
+    from mused_amd import synth
+
+    X = synth.gauss_stream(n, d, seed)[0] if tag == "gauss" else synth.blob_stream(n, d, seed, n_centres=4)[0]
+    assert synth.array_digest(X) == str(g[f"dense_{tag}_k{k}_digest"])
+    return X
 
 
 @pytest.fixture(scope="session")

@@ -95,6 +95,38 @@ def save(name, **arrs):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def case_cosine():
+    """a2: the cosine kernel of the reference's "text" branch (matrix_operations.py:91-110).
+    (1) the branch itself on synthetic ('title', 'description') strings, through the reference's own function;
+    (2) its arithmetic -- sklearn `cosine_similarity` + `np.argsort(-sim, axis=1)[:, :k + 1]` (:106-108) and the
+        write loop (:123-130) -- on dense feature rows, which is what modality_type="cosine" computes here."""
+    from sklearn.metrics.pairwise import cosine_similarity
+
+    out = {}
+    n, k, seed = 600, 20, 0
+    data, labels = synth.text_stream(n, seed)
+    A = quiet(ref_mo.create_adjacency_matrix, data, "text", k)
+    out["text_meta"] = np.array([n, k, seed])
+    out["text_digest"] = np.array(hashlib.sha256("\x1f".join(data.ravel()).encode()).hexdigest())
+    out["text_adj_hash"] = np.array(nbr_hash(A))
+    out["text_deg"] = A.sum(axis=1).astype(np.int32)
+    # all-blank input: no edges (:109-110)
+    out["blank_A"] = quiet(ref_mo.create_adjacency_matrix, np.array([["", ""]] * 4), "text", 2).astype(np.uint8)
+    for tag, (X, _) in (("gauss", synth.gauss_stream(500, 64, 0)), ("blob", synth.blob_stream(700, 96, 1, n_centres=4))):
+        for kk in (10, 50):
+            X64 = X.astype(np.float64)
+            sim = cosine_similarity(X64)
+            idx = np.argsort(-sim, axis=1)[:, : kk + 1]
+            Ad = np.zeros((len(X), len(X)))
+            for i, row in enumerate(idx):
+                for j in row:
+                    if i != j:
+                        Ad[i, j] = 1
+            out[f"dense_{tag}_k{kk}_hash"] = np.array(nbr_hash(Ad))
+            out[f"dense_{tag}_k{kk}_digest"] = np.array(synth.array_digest(X))
+    save("cosine", **out)
+
+
 def case_windows(tag, kind, n, d, W, ell, k, seed, two_mod=False, **kw):
     """Per-window records for the first few windows of a stream."""
     if two_mod:
@@ -106,6 +138,7 @@ def case_windows(tag, kind, n, d, W, ell, k, seed, two_mod=False, **kw):
     out = dict(
         meta=np.array([n, d, W, ell, k, seed]),
         kind=np.array(kind),
+        n_centres=np.array(kw.get("n_centres", 8)),
         input_digest=np.array([synth.array_digest(m) for m in mods]),
     )
     for w in range(n // W):
@@ -204,8 +237,19 @@ def case_edges():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated case tags to (re)generate")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    if only:
+        if "cosine" in only:
+            case_cosine()
+        if "c3_blob_s0" in only:   # BASELINE config 3 at its real shape
+            case_windows("c3_blob_s0", "blob", 10000, 4096, 10000, 256, 50, 0, n_centres=8, sep=2.0)
+        if "c4_twomod_s0" in only:  # BASELINE config 4 at its real shape (one of the 8 windows)
+            case_windows("c4_twomod_s0", "blob2", 10000, 512, 10000, 128, 50, 0, two_mod=True, n_centres=8)
+        return
     case_edges()
+    case_cosine()
     # BASELINE config 1 shapes: n=5000, d=64, W=500, ell=16, k=50
     for seed in (0, 1):
         case_windows(f"c1_gauss_s{seed}", "gauss", 1500, 64, 500, 16, 50, seed)
@@ -221,6 +265,8 @@ def main():
     if args.big:
         case_windows("c2_blob_s0", "blob", 10000, 1024, 10000, 128, 50, 0, n_centres=8, sep=2.0)
         case_windows("c2_gauss_s0", "gauss", 10000, 1024, 10000, 128, 50, 0)
+        case_windows("c3_blob_s0", "blob", 10000, 4096, 10000, 256, 50, 0, n_centres=8, sep=2.0)
+        case_windows("c4_twomod_s0", "blob2", 10000, 512, 10000, 128, 50, 0, two_mod=True, n_centres=8)
 
 
 if __name__ == "__main__":

@@ -90,7 +90,8 @@ def test_host_consumers_match_reference_goldens():
 def test_metadata_modalities_are_refused_not_silently_mishandled():
     from mused_amd import matrix_operations as mo
 
-    for t in ("location", "time", "username", "tags", "text"):
+    for t in ("location", "time", "username", "tags"):
         with pytest.raises(NotImplementedError):
             mo._metric_for(t)
     assert mo._metric_for("") == "l2" and mo._metric_for("anything") == "l2" and mo._metric_for("cosine") == "cosine"
+    assert mo._metric_for("text") == "cosine"  # host TF-IDF + the device cosine kernel (matrix_operations.py:91-110)

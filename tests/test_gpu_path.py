@@ -3,7 +3,7 @@ oracle and the committed golden vectors (which come from the reference's own mod
 import numpy as np
 import pytest
 
-from conftest import load_golden, nbr_hash, regen_inputs
+from conftest import COSINE_DENSE_CASES, cosine_dense_inputs, load_golden, nbr_hash, regen_inputs, text_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -69,6 +69,32 @@ def test_cosine_adjacency_matches_oracle(eng):
     ref = omo.create_adjacency_matrix(X, "cosine", 20)
     assert np.array_equal(_bool_from_adj(adj), ref.astype(bool))
     assert np.all(ref.sum(1) == 20)
+
+
+@pytest.mark.parametrize("tag,n,d,seed,k", COSINE_DENSE_CASES)
+def test_cosine_adjacency_matches_reference_golden(eng, tag, n, d, seed, k):
+    """a2 pinned: the device cosine kernel against sklearn cosine_similarity + argsort (reference arithmetic,
+    matrix_operations.py:106-108) recorded in tests/golden/cosine.npz."""
+    g = load_golden("cosine")
+    X = cosine_dense_inputs(g, tag, n, d, seed, k)
+    adj = eng.knn_adjacency(torch.from_numpy(X).cuda(), k, "cosine")
+    assert nbr_hash(_bool_from_adj(adj)) == str(g[f"dense_{tag}_k{k}_hash"])
+
+
+def test_text_modality_matches_reference_golden(eng):
+    """The reference's `text` branch (host TF-IDF + device cosine top-(k+1)) on synthetic string records,
+    incl. blank-title / blank-description / invalid rows."""
+    from mused_amd import matrix_operations as mo
+
+    g = load_golden("cosine")
+    data, _, n, k = text_inputs(g)
+    A = mo.create_adjacency_matrix(data, "text", k)
+    assert A.dtype == np.float64 and A.shape == (n, n)
+    assert nbr_hash(A) == str(g["text_adj_hash"])
+    assert np.array_equal(mo.create_adjacency_matrix(np.array([["", ""]] * 4), "text", 2).astype(np.uint8), g["blank_A"])
+    for t in ("location", "time", "username", "tags"):
+        with pytest.raises(NotImplementedError):
+            mo.create_adjacency_matrix(np.zeros((4, 2)), t, 2)
 
 
 def test_rsvd_intermediate_components(eng):
@@ -229,22 +255,27 @@ def test_swfd_lanes_equal_independent_sketches():
 
 
 # ---------------------------------------------------------------- BASELINE config-2 full size ----
-@pytest.mark.parametrize("name", ["c2_blob_s0", "c2_gauss_s0"])
+@pytest.mark.parametrize("name", ["c2_blob_s0", "c2_gauss_s0", "c3_blob_s0", "c4_twomod_s0"])
 def test_full_size_window_matches_reference_golden(name):
-    """W = 10,000, d = 1024, l = 128, k = 50 (BASELINE.json configs[1]): neighbour hash, R, the 128
-    singular values, embedding samples and the 10,000 k-means labels of the REFERENCE reproduced."""
+    """One full-size window of BASELINE.json configs[1] (W = 10,000, d = 1024, l = 128), configs[2] (d = 4096,
+    l = 256) and configs[3] (two 512-d modalities, OR-fused, l = 128), k = 50: neighbour hashes, fused hash, R, the
+    l singular values, embedding samples and the 10,000 k-means labels of the REFERENCE reproduced."""
     from mused_amd import matrix_operations as mo
     from mused_amd.engine import WindowEngine
 
     g = load_golden(name)
     mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
     eng = WindowEngine(W)
-    adj = eng.knn_adjacency(torch.from_numpy(mods[0]).cuda(), k, "l2")
-    assert nbr_hash(_bool_from_adj(adj)) == str(g["w0_adj_hash"][0])
-    fused = eng.fuse([adj])
+    adjs = []
+    for m, hh in zip(mods, g["w0_adj_hash"]):
+        adj = eng.knn_adjacency(torch.from_numpy(m).cuda(), k, "l2")
+        assert nbr_hash(_bool_from_adj(adj)) == str(hh)
+        adjs.append(adj)
+    fused = eng.fuse(adjs)
+    assert nbr_hash(_bool_from_adj(fused)) == str(g["w0_fused_hash"])
     assert eng.max_row_sq_norm(fused) == pytest.approx(float(g["w0_R"]), rel=1e-12)
-    emb, sig = eng.svd_reduce(fused, ell, seed, nnz_cap=W * k)
-    assert eng.rsvd_status()[0] == 0
+    emb, sig, flags = eng.svd_reduce(fused, ell, seed, nnz_cap=W * k * len(mods), want_flags=True)
+    assert int(flags.cpu()[0]) == 0
     emb, sig = emb.cpu().numpy(), sig.cpu().numpy()
     np.testing.assert_allclose(sig, g["w0_sigma"], rtol=1e-8)  # north star: 1e-4 rel
     rows = g["w0_emb_rows"]
@@ -252,6 +283,70 @@ def test_full_size_window_matches_reference_golden(name):
     km = mo.perform_clustering(emb, len(np.unique(labels)), seed)
     assert np.array_equal(km.astype(np.int32), g["w0_kmeans_labels"])  # bit-exact event indices
     eng.close()
+
+
+def test_headline_shape_swfd_lanes_match_oracle_and_single_sketches():
+    """The configuration bench.py times -- N = 10,000, d = 1024, l = 128, several lanes advanced in lock-step
+    with input-block pre-rotation and duplicate-level skipping on (the defaults) -- against oracle/swfd_oracle.py
+    (sigma, level, covariance) and, bit for bit, against single-lane handles, over the first 1,152 rows
+    (9 rotations of all 28 sketches per lane) of three different windows of the benchmark stream."""
+    from mused_amd import synth
+    from mused_amd.swfd import SeqBasedSWFD as Dev
+    from oracle.swfd_oracle import SeqBasedSWFD as Ora
+
+    W, d, ell, B, rows = 10000, 1024, 128, 3, 1152
+    Xs = [synth.stream_window("blob", t, W, d, 0)[0][:rows] for t in range(B)]
+    R = float((synth.stream_window("blob", 0, W, d, 0)[0].astype(np.float64) ** 2).sum(1).max())
+    lanes = Dev(N=W, R=R, d=d, sketch_dim=ell, lanes=B)
+    singles = [Dev(N=W, R=R, d=d, sketch_dim=ell) for _ in range(B)]
+    oras = [Ora(N=W, R=R, d=d, sketch_dim=ell) for _ in range(B)]
+    assert lanes.L == oras[0].L == 14
+    X = torch.from_numpy(np.stack(Xs)).cuda()
+    t = 0
+    for step in (640, 512):  # 5 whole blocks (pre-rotated as one batch), then 4
+        lanes.fit_lanes(X[:, t : t + step])
+        for b in range(B):
+            singles[b].fit(X[b, t : t + step])
+            oras[b].fit(Xs[b][t : t + step])
+        t += step
+        Bl, sl, ll, dl = lanes.get()
+        for b in range(B):
+            Bs, ss, ls, ds = singles[b].get()
+            assert int(ll[b]) == ls and np.array_equal(Bl[b], Bs) and np.array_equal(sl[b], ss) and dl[b] == ds
+            Bo, so, lo, do = oras[b].get()
+            assert ls == lo
+            np.testing.assert_allclose(ss, so, rtol=0, atol=1e-8 * so[0])  # north star: 1e-4 rel
+            np.testing.assert_allclose(Bs.T @ Bs, Bo.T @ Bo, rtol=0, atol=1e-8 * so[0] ** 2)
+            assert abs(ds - do) <= 1e-8 * so[0] ** 2
+    lanes.close()
+    for sk in singles:
+        sk.close()
+
+
+def test_rsvd_edge_overflow_is_flagged_and_memory_safe(eng):
+    """More edges than nnz_cap (cosine selects k + 1 per row; a zero row is not its own nearest): the neighbour lists
+    are truncated inside their buffer, flags[0] is raised and the host check raises; with the right cap it is clean."""
+    from mused_amd._lib import MusedError
+    from mused_amd.engine import WindowEngine
+
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((600, 16)).astype(np.float32)
+    X[::7] = 0.0  # zero-norm rows: cosine 0 to every row, ties to the lowest columns -> k + 1 edges
+    k = 9
+    adj = eng.knn_adjacency(torch.from_numpy(X).cuda(), k, "cosine")
+    nnz = int(adj.degrees()[2][1].item())
+    assert nnz > 600 * k
+    e2 = WindowEngine(600)
+    emb, sig, flags = e2.svd_reduce(adj, 4, 0, nnz_cap=600 * k, want_flags=True)  # too small on purpose
+    torch.cuda.synchronize()
+    assert int(flags.cpu()[0]) != 0
+    with pytest.raises(MusedError):
+        WindowEngine.check_rsvd_flags(flags.cpu().numpy())
+    e2.close()
+    e3 = WindowEngine(600)
+    emb, sig, flags = e3.svd_reduce(adj, 4, 0, nnz_cap=600 * (k + 1), want_flags=True)
+    assert int(flags.cpu()[0]) == 0 and bool(torch.isfinite(emb).all())
+    e3.close()
 
 
 def test_full_size_swfd_properties():

@@ -51,6 +51,32 @@ def test_process_streaming_data_signature_and_hopping_windows():
     assert res["processing_time"] > 0
 
 
+def test_stream_with_nonfinite_rows_and_modality_types():
+    """The drop-in window loop filters non-finite rows like the reference (matrix_operations.py:114-115), runs the
+    "text" modality (host TF-IDF + device cosine) next to a numeric one, and refuses the metadata modality types that
+    are not on the device path instead of silently treating them as Euclidean rows."""
+    from mused_amd import synth
+    from mused_amd.pipeline import process_streaming_data
+    from oracle import mo_oracle as omo
+
+    X, labels = synth.blob_stream(900, 20, 4, n_centres=3)
+    X = X.astype(np.float64)
+    X[5, 3] = np.nan
+    X[301, 0] = np.inf
+    X[777, 19] = -np.inf
+    res = process_streaming_data({}, [X], [""], 300, 6, 15, 3, 0, "sSVDMC", labels, 1, 0.0, "types", False, 1.5, 2)
+    ref = omo.process_streaming_data([X], [""], 300, 6, 15, 0, "sSVDMC", labels)
+    assert np.array_equal(res["all_clusters"], ref)
+    text, tl = synth.text_stream(600, 1)
+    Xn = synth.blob_stream(600, 12, 1, n_centres=4)[0].astype(np.float64)
+    res = process_streaming_data({}, [Xn, text], ["", "text"], 300, 6, 15, 4, 0, "sSVDMC", tl, 1, 0.0, "types", False, 1.5, 2)
+    ref = omo.process_streaming_data([Xn, text], ["", "text"], 300, 6, 15, 0, "sSVDMC", tl)
+    assert np.array_equal(res["all_clusters"], ref)
+    for t in ("location", "time", "username", "tags"):
+        with pytest.raises(NotImplementedError):
+            process_streaming_data({}, [X], [t], 300, 6, 15, 3, 0, "sSVDMC", labels, 1, 0.0, "types", False, 1.5, 2)
+
+
 def test_swfdmc_approach_matches_oracle_pipeline():
     """approach SWFDMC (main.py:58-76): SWFD over the rows of the fused matrix (d = W), R from the first
     window only, sketch transposed to (W, l), labels equal to the CPU oracle pipeline."""

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import load_golden, nbr_hash, regen_inputs
+from conftest import COSINE_DENSE_CASES, cosine_dense_inputs, load_golden, nbr_hash, regen_inputs, text_inputs
 from oracle import mo_oracle as mo
 
 WINDOW_CASES = ["c1_gauss_s0", "c1_gauss_s1", "c1_blob_s0", "c1_blob_s1", "c1_fd_s0", "c4s_twomod_s0"]
@@ -58,6 +58,28 @@ def test_stream_event_labels_bit_exact(name):
     assert out.dtype == np.int64 or out.dtype == np.int32
     assert np.array_equal(out.astype(np.int64), g["all_clusters"])
     assert hashlib.sha256(out.astype(np.int64).tobytes()).hexdigest() == str(g["labels_sha"])
+
+
+def test_text_branch_matches_reference():
+    """a2: the reference's own `text` branch (matrix_operations.py:91-110) on synthetic string records."""
+    g = load_golden("cosine")
+    data, _, n, k = text_inputs(g)
+    A = mo.create_adjacency_matrix(data, "text", k)
+    assert nbr_hash(A) == str(g["text_adj_hash"])
+    assert np.array_equal(A.sum(axis=1).astype(np.int32), g["text_deg"])
+    invalid = np.where(~np.any(data != "", axis=1))[0]
+    assert len(invalid) > 0 and A[invalid].sum() == 0 and A[:, invalid].sum() == 0
+    assert np.array_equal(mo.create_adjacency_matrix(np.array([["", ""]] * 4), "text", 2).astype(np.uint8), g["blank_A"])
+
+
+@pytest.mark.parametrize("tag,n,d,seed,k", COSINE_DENSE_CASES)
+def test_cosine_kernel_matches_reference_arithmetic(tag, n, d, seed, k):
+    """a2: sklearn `cosine_similarity` + `argsort(-sim)[:, :k+1]` + the write loop (matrix_operations.py:106-108,
+    123-130) on dense rows == the oracle's "cosine" type."""
+    g = load_golden("cosine")
+    X = cosine_dense_inputs(g, tag, n, d, seed, k)
+    A = mo.create_adjacency_matrix(X.astype(np.float64), "cosine", k)
+    assert nbr_hash(A) == str(g[f"dense_{tag}_k{k}_hash"])
 
 
 def test_edges():
