@@ -4,19 +4,22 @@ BASELINE.json config-2 workload: synthetic stream, d = 1024, l = 128, window W =
 
 One STEP = one window of W rows, already resident in HBM, through the whole path:
     SeqBasedSWFD over the W feature rows (append + get)         [a5-a7]
-    Euclidean kNN adjacency of the window (fp64 MFMA scores + exact selection)   [a1]
+    Euclidean kNN adjacency of the window (fp64 MFMA scores + exact selection), per modality   [a1]
     fusion / R                                                  [a3, a4]
     randomized-SVD eigenstep on the fused adjacency             [a8]
     k-means + Hungarian matching on the host (sklearn / SciPy)  [a10]  -> event labels
 `value` = rows of all ranks / wall time of the K timed steps (max over ranks), inputs resident.
 
-In-GPU concurrency (one rank): the K windows are dealt to B "lanes" (contiguous blocks of the stream, each preceded by
-its warm-up = halo window); the sketches of the lanes advance in lockstep inside shared launches, in THREE groups of
-lanes on three HIP streams, while a fourth, high-priority stream runs adjacency -> eigenstep of the same windows and a
-pool of host workers the k-means / matching.  `roofline` is the Jacobi round kernel as it runs in the timed region (per
-launch, next to the other group's launches), `roofline_isolated` the same kernel with the GPU to itself.
+Stream layout (the same for every lane / rank count): rank r owns the K timed windows [r K, (r + 1) K) of the
+seeded stream; inside a rank they are dealt as CONTIGUOUS blocks to B = --lanes "lanes" (fixed: it does not depend
+on --steps), each preceded by its halo / warm-up windows (the windows just before its block).  The sketches of the
+lanes advance in lock-step inside shared launches, in up to three groups on three HIP streams; a fourth,
+high-priority stream runs adjacency -> eigenstep of the same windows and a pool of host workers the k-means /
+matching.  When K is not a multiple of B the shorter lanes idle in the last lock-step (`config.padded_window_slots`
+says how many slots): that time is part of `value`.  `single_lane` is what ONE stream consumed strictly in order gets
+(no batching across windows): rows/s and p50 window latency.
 
-    python bench.py                       # 1 GPU, K = 9, W = 1
+    python bench.py                       # 1 GPU, K = 20, W = 5 (what the driver runs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -24,6 +27,8 @@ Multi-GPU: every rank owns a contiguous block of windows of the stream (mused_am
 weak scaling, no data-path collective; one all-gather of raw labels at the end.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -42,27 +47,37 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration `metric` is quoted on
-    "c2": dict(W=10000, d=1024, ell=128, k=50, name="synthetic d=1024 l=128 window=10000 k=50 (BASELINE config 2)"),
-    # BASELINE.json configs[2] (secondary: the order-512 / 1024 eigenproblems still run on the row-per-thread kernel)
-    "c3": dict(W=10000, d=4096, ell=256, k=50, name="synthetic d=4096 l=256 window=10000 k=50 (BASELINE config 3)"),
+    "c2": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=10,
+               name="synthetic d=1024 l=128 window=10000 k=50 (BASELINE config 2)"),
+    # BASELINE.json configs[2]
+    "c3": dict(W=10000, dims=(4096,), ell=256, k=50, lanes=4,
+               name="synthetic d=4096 l=256 window=10000 k=50 (BASELINE config 3)"),
+    # BASELINE.json configs[3]: two 512-d modalities -> two kNN adjacencies -> OR-fusion (reference semantics,
+    # main.py:45-56); the feature-row sketch sees the 1024-d concatenated rows
+    "c4": dict(W=10000, dims=(512, 512), ell=128, k=50, lanes=10,
+               name="synthetic two modalities d=512+512 l=128 window=10000 k=50 (BASELINE config 4)"),
     # small plumbing case (configs[0] shapes) for quick checks
-    "c1": dict(W=500, d=64, ell=16, k=50, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
+    "c1": dict(W=500, dims=(64,), ell=16, k=50, lanes=4, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
 }
+PRE_STREAM = 1 << 20  # window indices of warm-up windows that would precede window 0 of the stream
+FP64_PEAK_TFLOPS = 78.6  # gfx950: the fp64 vector-FMA peak and the fp64 MFMA peak are the same number
+HBM_PEAK_GBS = 8000.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blob", choices=["blob", "gauss", "fd"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
-    ap.add_argument("--lanes", type=int, default=9,
+    ap.add_argument("--no-single-lane", action="store_true", help="skip the in-order single-lane measurement")
+    ap.add_argument("--lanes", type=int, default=0,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
-                         "launches (1 = strictly one window at a time)")
+                         "launches (0 = the workload's default; 1 = strictly one window at a time)")
     ap.add_argument("--sketch-groups", type=int, default=0,
                     help="independent groups of lanes, each on its own HIP stream / host thread (0 = auto: 3 groups "
                          "from 6 lanes, 2 from 4): their launches interleave on the GPU, so the Gram / rotate GEMMs of one "
@@ -85,23 +100,41 @@ def hip_event_ms(fn, stream, reps=1):
     return e0.elapsed_time(e1) / reps
 
 
-def stage_profile(cfg, X, pipe, sketch, rows_all):
-    """Per-stage device times (ms, HIP events on the launch stream) for one resident window, plus
-    the live roofline measurement of the dominant kernels."""
-    import ctypes as C
+def window_rows(cfg, kind, idx, seed):
+    """(rows float32 (W, sum(dims)), labels) of window `idx` of the benchmark stream."""
+    from mused_amd import synth
+
+    if len(cfg["dims"]) == 1:
+        return synth.stream_window(kind, idx, cfg["W"], cfg["dims"][0], seed)
+    return synth.stream_window_mods(idx, cfg["W"], cfg["dims"], seed)
+
+
+def split_mods(cfg, rows):
+    """Column slices of a resident (W, sum(dims)) window: one per modality (views, no copy)."""
+    out, c = [], 0
+    for dm in cfg["dims"]:
+        out.append(rows[:, c : c + dm])
+        c += dm
+    return out
+
+
+def stage_profile(cfg, X, pipe, sketch, rows_grp):
+    """Per-stage device times (ms, HIP events on the launch stream) for one resident window."""
+    import ctypes as C  # noqa: F401
 
     import torch
 
     from mused_amd import _lib
     from mused_amd.engine import ptr, stream_ptr
 
-    W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
+    W, ell, k = cfg["W"], cfg["ell"], cfg["k"]
     eng = pipe.eng
     st = torch.cuda.current_stream()
     out = {}
-    # similarity GEMM alone: row norms + fp64 MFMA X X^T with the distance epilogue
-    dt = _lib.F32 if X.dtype == torch.float32 else _lib.F64
-    f_scores = lambda: _lib.call("mused_pairwise_scores", ptr(X), dt, W, d, X.stride(0), 0, ptr(eng.norms),
+    X0 = split_mods(cfg, X)[0]
+    d0 = X0.shape[1]
+    dt = _lib.F32 if X0.dtype == torch.float32 else _lib.F64
+    f_scores = lambda: _lib.call("mused_pairwise_scores", ptr(X0), dt, W, d0, X0.stride(0), 0, ptr(eng.norms),
                                  ptr(eng.scores), stream_ptr())
     f_scores()
     out["scores_gemm_ms"] = hip_event_ms(f_scores, st, 3)
@@ -110,28 +143,17 @@ def stage_profile(cfg, X, pipe, sketch, rows_all):
     f_sel = lambda: _lib.call("mused_select_k_smallest", ptr(eng.scores), W, W, k, None, ptr(mask), w, stream_ptr())
     f_sel()
     out["select_ms"] = hip_event_ms(f_sel, st, 3)
-    adj = eng.knn_adjacency(X, k)
-    f_rsvd = lambda: eng.svd_reduce(adj, ell, pipe.seed, nnz_cap=W * k)
+    adj = eng.knn_adjacency(X0, k)
+    f_rsvd = lambda: eng.svd_reduce(adj, ell, pipe.seed, nnz_cap=W * k * len(cfg["dims"]))
     f_rsvd()
     out["rsvd_ms"] = hip_event_ms(f_rsvd, st, 2)
     if sketch is not None:
-        f_app = lambda: sketch.fit_lanes(rows_all[:, -1])
+        f_app = lambda: sketch.fit_lanes(rows_grp[:, -1])
         out["swfd_append_ms_group0_alone"] = hip_event_ms(f_app, st, 1)
         f_get = lambda: sketch.get_device()
         out["swfd_query_ms_group0_alone"] = hip_event_ms(f_get, st, 1)
         out["swfd_levels"] = sketch.L
         out["swfd_lanes_group0"] = sketch.lanes
-    if sketch is not None and os.environ.get("MUSED_BENCH_LATENCY_PROBE"):
-        # latency-oriented setting for comparison (not the throughput configuration that is timed; off by default so
-        # that a rocprofv3 --stats run of this script averages the same launches as the live timing): ONE window at a
-        # time through a single-lane sketch -- what a window costs when nothing is batched across windows
-        from mused_amd.swfd import SeqBasedSWFD
-
-        one = SeqBasedSWFD(N=W, R=sketch.R, d=d, sketch_dim=ell, lanes=1)
-        one.fit(X)
-        f_one = lambda: (one.fit(X), one.get_device())
-        out["swfd_window_ms_single_lane"] = hip_event_ms(f_one, st, 1)
-        one.close()
     return out
 
 
@@ -139,8 +161,8 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
     """The CPU oracle (oracle/*.py, a port of the reference path pinned to its golden vectors) timed
     on this box's host cores over a bounded sample of the same workload.  BLAS / OpenMP pools are capped at
     16 threads (a one-GPU share of the host): left at one thread per visible core (256 here) the same sample
-    runs ~10x slower, which would flatter the GPU."""
-    from mused_amd import synth
+    runs ~10x slower, which would flatter the GPU.  The SWFD part is this repo's OWN specification of the absent
+    `swfd` submodule (parity unpinned): `value_without_swfd` is the figure that rests on reference-pinned code only."""
     from oracle import mo_oracle as omo
     from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
 
@@ -151,11 +173,14 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
         limiter = threadpool_limits(limits=threads)
     except Exception:
         limiter, threads = None, os.cpu_count() or 1
-    W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
-    X, labels = synth.stream_window(kind, 0, W, d, seed)
+    W, ell, k = cfg["W"], cfg["ell"], cfg["k"]
+    X, labels = window_rows(cfg, kind, 0, seed)
+    mods, c = [], 0
+    for dm in cfg["dims"]:
+        mods.append(X[:, c : c + dm].astype(np.float64))
+        c += dm
     t0 = time.perf_counter()
-    A = omo.create_adjacency_matrix(X.astype(np.float64), "", k)
-    F = omo.fuse_matrices([A])
+    F = omo.fuse_matrices([omo.create_adjacency_matrix(m, "", k) for m in mods])
     omo.max_row_sq_norm(F)
     t1 = time.perf_counter()
     emb, _, _ = omo.randomized_svd_reduce(F, ell, seed)
@@ -167,7 +192,7 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
     if with_swfd:
         X64 = X.astype(np.float64)
         R = float((X64**2).sum(1).max())
-        sk = OraSWFD(N=W, R=R, d=d, sketch_dim=ell)
+        sk = OraSWFD(N=W, R=R, d=X.shape[1], sketch_dim=ell)
         swfd_rows = min(W, 4 * ell)  # 4 rotations of every level; steady-state cost per row is constant
         ts = time.perf_counter()
         sk.fit(X64[:swfd_rows])
@@ -186,13 +211,20 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
                   f"({t_swfd_per_row * 1e3:.2f} ms/row) and extrapolated to the window; BLAS/OpenMP pools capped at "
                   f"{threads} threads",
         "window_seconds": window_s,
+        "value_without_swfd": W / (t3 - t0),
     }
+
+
+def newest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
 
 
 def main():
     args = parse()
     cfg = dict(WORKLOADS[args.workload])
-    W, d, ell, k = cfg["W"], cfg["d"], cfg["ell"], cfg["k"]
+    W, ell, k, dims = cfg["W"], cfg["ell"], cfg["k"], cfg["dims"]
+    D, M = sum(dims), len(dims)
 
     import torch
     import torch.distributed as dist
@@ -218,42 +250,47 @@ def main():
 
     from mused_amd import distributed as mdist
     from mused_amd import matrix_operations as mo
-    from mused_amd import synth
     from mused_amd.pipeline import StreamPipeline
 
     K, Wu = args.steps, args.warmup
-    # Window-level concurrency on one GPU: the rank's K timed windows are split into B contiguous
-    # blocks ("lanes").  The B sketch sets advance in LOCKSTEP inside the same kernel launches
-    # (mused_swfd_*_lanes) on one HIP stream / host thread; adjacency + eigenstep + labels of the same
-    # windows run on a second stream / host thread.  Every block is preceded in the stream by its Wu
-    # warm-up windows, which double as the SWFD halo (mused_amd/distributed.py).
-    # lanes: at most --lanes; the count that minimises (lock-step steps) x (time of a step of B lanes; measured at
-    # config 2 with two sketch groups: 400 ms at B = 3, 463 at 5, 712 at 9 -- about 250 + 51 B: the per-lane cost falls
-    # with B).
-    cand = range(1, max(1, min(args.lanes, K)) + 1)
-    B = min(cand, key=lambda b: ((-(-K // b)) * (250.0 + 51.0 * b), -b))
-    blks = [K // B + (1 if p < K % B else 0) for p in range(B)]   # timed windows per lane
+    # ---- stream layout: lane count is a property of the workload, not of --steps -------------------------------
+    B = max(1, min(args.lanes if args.lanes > 0 else cfg["lanes"], K))
+    g0 = rank * K                                      # first timed window of this rank (global stream index)
+    blocks = [mdist.block_partition(K, B, p) for p in range(B)]
+    blks = [b1 - b0 for b0, b1 in blocks]              # timed windows per lane (differ by at most one)
     blk = max(blks)
-    T = Wu + blk                      # lock-step groups (a lane with fewer windows repeats its last one: padding)
-    per_rank = K + B * Wu
-    first = rank * per_rank           # global window index of lane 0, window 0
-    bases, b0 = [], first
-    for p in range(B):
-        bases.append(b0)
-        b0 += Wu + blks[p]
-    host = [[synth.stream_window(args.kind, bases[p] + t, W, d, args.seed) for t in range(Wu + blks[p])] for p in range(B)]
-    rows_all = torch.empty((B, T, W, d), dtype=torch.float32, device="cuda")   # resident before timing
+    T = Wu + blk                                       # lock-steps (a shorter lane repeats its last window: padding)
+    padded_slots = sum(blk - b for b in blks)
+
+    def lane_window_index(p, t):
+        """global stream index of lock-step t of lane p (t < Wu: its warm-up / halo windows)"""
+        s = g0 + blocks[p][0]
+        idx = s - Wu + min(t, Wu + blks[p] - 1)
+        return idx if idx >= 0 else PRE_STREAM - idx
+    host = {}
     for p in range(B):
         for t in range(T):
-            rows_all[p, t].copy_(torch.from_numpy(host[p][min(t, Wu + blks[p] - 1)][0]))
-    labels = [[l for _, l in hp] for hp in host]
+            gi = lane_window_index(p, t)
+            if gi not in host:
+                host[gi] = window_rows(cfg, args.kind, gi, args.seed)
+    rows_all = torch.empty((B, T, W, D), dtype=torch.float32, device="cuda")   # resident before timing
+    for p in range(B):
+        for t in range(T):
+            rows_all[p, t].copy_(torch.from_numpy(host[lane_window_index(p, t)][0]))
+    labels = [[host[lane_window_index(p, t)][1] for t in range(T)] for p in range(B)]
 
     sketches, grp = [], []   # one sketch object per group of lanes; grp[g] = (first lane, one past the last lane)
+    R = 0.0
     if not args.no_swfd:
         from mused_amd.swfd import SeqBasedSWFD
 
         # R (main.py:61 analogue for the feature sketch) is fixed by window 0 of the stream: rank 0 owns it
-        R0 = float((rows_all[0, 0].double() ** 2).sum(dim=1).max().item()) if rank == 0 else 0.0
+        if rank == 0:
+            x0 = torch.from_numpy(window_rows(cfg, args.kind, 0, args.seed)[0]).cuda()
+            R0 = float((x0.double() ** 2).sum(dim=1).max().item())
+            del x0
+        else:
+            R0 = 0.0
         R = mdist.broadcast_scalar(R0, 0, device=coll_dev) if world > 1 else R0
         G = args.sketch_groups if args.sketch_groups > 0 else (3 if B >= 6 else (2 if B >= 4 else 1))
         G = max(1, min(G, B))
@@ -261,22 +298,18 @@ def main():
         for g in range(G):
             l1 = l0 + B // G + (1 if g < B % G else 0)
             grp.append((l0, l1))
-            sketches.append(SeqBasedSWFD(N=W, R=R, d=d, sketch_dim=ell, lanes=l1 - l0))
+            sketches.append(SeqBasedSWFD(N=W, R=R, d=D, sketch_dim=ell, lanes=l1 - l0))
             l0 = l1
     sketch = sketches[0] if sketches else None
     # different priorities -> different HIP hardware queues (two default-priority streams can land on the
-    # same queue and then run strictly in order)
-    # the adjacency / eigenstep stream gets the HIGH priority: a chain of ~3600 small dependent launches per window,
-    # each of which would otherwise queue behind a full wave of sketch workgroups
+    # same queue and then run strictly in order); the adjacency / eigenstep stream gets the HIGH priority: a chain of
+    # ~1600 small dependent launches per window, each of which would otherwise queue behind a full wave of sketch
+    # workgroups
     hi_main = os.environ.get('MUSED_BENCH_PRIO', 'main') == 'main'
-    # (diagnostic: idle extra streams, to see how robust the stream -> hardware-queue mapping is)
-    _extra = [torch.cuda.Stream() for _ in range(int(os.environ.get('MUSED_BENCH_EXTRA_STREAMS', '0')))]
-    for _e in _extra:
-        with torch.cuda.stream(_e):
-            torch.zeros(1, device='cuda')
     st_main = torch.cuda.Stream(priority=-1 if hi_main else 0)
     st_sketch = [torch.cuda.Stream(priority=0 if hi_main else -1) for _ in sketches]
-    pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", feature_sketch=False, async_labels=True, stream=st_main)
+    pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", modality_types=[""] * M, feature_sketch=False,
+                          async_labels=True, stream=st_main, assume_finite=True)
     torch.cuda.synchronize()
 
     import threading
@@ -284,6 +317,7 @@ def main():
     sk_events = {}   # (group, t) -> (event, enqueue time)
     sk_out = {}
     refs = [{"ev": None, "t": 0.0} for _ in sketches]
+    trace_on = bool(os.environ.get("MUSED_BENCH_TRACE"))
 
     def drive_sketch(g, lo, hi):
         torch.cuda.set_device(local_rank)  # the current device is per host thread
@@ -302,23 +336,19 @@ def main():
                 sk_events[(g, t)] = (ev, t_enq)
             if hi > lo:
                 sk_events[(g, hi - 1)][0].synchronize()
-        if os.environ.get("MUSED_BENCH_TRACE"):
+        if trace_on:
             print(f"[trace] sketch group {g} done {time.perf_counter() - ref['t']:.3f}s after its start", file=sys.stderr)
 
+    def trigger_of(p, t):
+        return (lane_window_index(p, t) + 1) * W - 1
+
     def drive_main(lo, hi):
-        # window order of the label chain: lane-major within the rank is restored after the run
         torch.cuda.set_device(local_rank)
-        tm0 = time.perf_counter()
         for t in range(lo, hi):
             for p in range(B):
                 if t < Wu + blks[p]:
-                    pipe.process_window([rows_all[p, t]], labels[p][t], trigger=(bases[p] + t + 1) * W - 1)
-                    if os.environ.get("MUSED_BENCH_TRACE"):
-                        print(f"[trace] main enqueued window ({t},{p}) at {time.perf_counter() - tm0:.3f}s", file=sys.stderr)
+                    pipe.process_window(split_mods(cfg, rows_all[p, t]), labels[p][t], trigger=trigger_of(p, t))
         pipe.flush()
-        if os.environ.get("MUSED_BENCH_TRACE"):
-            print(f"[trace] main thread done {time.perf_counter() - tm0:.3f}s; label latencies {[round(x, 3) for x in pipe.latencies[-B:]]}"
-                  f" kmeans ms {[round(x) for x in pipe.host_ms['kmeans'][-B:]]} match ms {[round(x) for x in pipe.host_ms['match'][-B:]]}", file=sys.stderr)
 
     def run_range(lo, hi):
         ths = [threading.Thread(target=drive_sketch, args=(g, lo, hi)) for g in range(len(sketches))]
@@ -350,15 +380,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    S = B
 
-    # label chain across ranks (outside the timed region: W ints per window)
-    # traces were appended in (t, lane) order; the stream order is lane-major
+    # label chain across ranks (outside the timed region: W ints per window), in stream order
     by_trigger = {tr["trigger"]: tr["raw"] for tr in pipe.trace}
-    raw_local = np.array([by_trigger[(bases[p] + t + 1) * W - 1] for p in range(B) for t in range(Wu, Wu + blks[p])],
-                         dtype=np.int64)
-    counts = [K] * world
-    raw_all = mdist.gather_raw_labels(raw_local, counts, device=coll_dev)
+    raw_local = np.array([by_trigger[trigger_of(p, t)] for p in range(B) for t in range(Wu, Wu + blks[p])], dtype=np.int64)
+    raw_all = mdist.gather_raw_labels(raw_local, [K] * world, device=coll_dev)
     all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
 
     if rank == 0:
@@ -375,11 +401,43 @@ def main():
         ev_pairs = pipe.eng.score_events
         pipe.eng.score_events = None
         gemm_live_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None
-        # the live Jacobi timing covers the timed region only: read it before the stand-alone stage runs below
+        # the live Jacobi timing covers the timed region only: read it before the stand-alone runs below
         osj_reads = []
         for sk in sketches:
             osj_reads.append(sk.profile_read())
             sk.profile(False)
+
+        # ---- what ONE stream consumed in order gets: a single-lane sketch beside the main path, window by window ----
+        single = None
+        if sketches and not args.no_single_lane:
+            from mused_amd.swfd import SeqBasedSWFD
+
+            one = SeqBasedSWFD(N=W, R=R, d=D, sketch_dim=ell, lanes=1)
+            one.profile(True)
+            nwin = min(T, 4)
+            lats = []
+            for t in range(T - nwin, T):   # the first is a warm-up (graph upload) and the sketch's halo window
+                ts = time.perf_counter()
+
+                def _sk():
+                    torch.cuda.set_device(local_rank)
+                    with torch.cuda.stream(st_sketch[0]):
+                        one.fit(rows_all[0, t])
+                        one.get_device()
+                        st_sketch[0].synchronize()
+                th = threading.Thread(target=_sk)
+                th.start()
+                pipe.process_window(split_mods(cfg, rows_all[0, t]), labels[0][t], trigger=-(t + 1))
+                pipe.flush()
+                th.join()
+                lats.append(time.perf_counter() - ts)
+            other_reads.append(one.profile_read())
+            one.close()
+            p50 = float(np.median(lats[1:])) if len(lats) > 1 else float(lats[0])
+            single = {"rows_per_s": W / p50, "p50_window_ms": 1e3 * p50, "windows_timed": max(1, len(lats) - 1),
+                      "note": "one window at a time, strictly in order: a 1-lane sketch on its stream beside adjacency -> "
+                              "eigenstep -> labels of the same window; nothing batched across windows"}
+
         if sketch is not None:
             sketch.profile(True)
         stages = stage_profile(cfg, rows_all[0, -1], pipe, sketch, rows_all[grp[0][0]:grp[0][1]] if grp else rows_all)
@@ -388,16 +446,20 @@ def main():
             sketch.profile(False)
         stages["swfd_groups"] = [b - a for a, b in grp]
         stages["scores_gemm_ms_live_timed_region"] = gemm_live_ms
-        # ---- rooflines (both measured live with HIP events on the launch streams over the timed region) ----
-        # (1) dominant kernel by time: osjw_kernel, one block-pair round of the one-sided Jacobi of the FD
-        #     rotation.  Per launch it streams every Gram matrix that is still iterating from memory and back
-        #     (16 n^2 B per matrix): load/store phases around a VALU-issue-bound chain of
-        #     32 (round 0: 63) dependent pair-steps.
-        roof = None
+        L_sk = stages.get("swfd_levels") or 0
+
+        # ---- rooflines (measured live with HIP events on the launch streams over the timed region) ----
+        # (1) dominant kernel by time: osjw_kernel, one block-pair round of the one-sided Jacobi of the FD rotation.
+        #     It contains no MFMA: a VALU-issue-bound chain of dependent pair-steps between a load and a store phase
+        #     (DESIGN.md section 5).  Priced on its executed fp64 flops against the fp64 rate of the chip (vector FMA and
+        #     MFMA peaks coincide at 78.6 TF/s on gfx950); `roofline_hbm` prices the same launches on the bytes they move.
+        roof = roof_hbm = None
+        n2 = 2 * ell
+        # one sweep = n (n - 1) / 2 column pairs x (2 n flop dot product + 4 n flop rotation), spread over nb - 1 launches
+        # (orders <= 256; nb = n / 32 column blocks) or nb launches (orders 320-512: one more for the pairs inside the blocks)
+        nb = max(2, -(-n2 // 64) * 2)
+        flops_per_matrix_launch = (n2 * (n2 - 1) // 2) * (6.0 * n2) / (nb - 1 if n2 <= 256 else nb)
         if sketches:
-            # all groups together: average duration and average algorithmic bytes of ONE launch (what rocprofv3 --stats
-            # averages too).  With G groups on G streams up to G such launches share the GPU at any time, so the
-            # per-launch rate is about 1 / G of what the kernel sustains across the streams (`achieved_all_streams`).
             osj_ms = osj_launches = 0
             osj_total_bytes = 0.0
             for ms_g, n_g, b_g in osj_reads:
@@ -409,82 +471,61 @@ def main():
                 osj_bytes = osj_total_bytes / osj_launches
                 gbs = osj_bytes / (osj_us * 1e-6) / 1e9
                 mats_per_launch = np.mean([sk.lanes * 2 * sk.L for sk in sketches])
-                per_matrix = 16.0 * (2 * ell) ** 2          # every matrix read + written once per launch
-                active_mats = osj_bytes / per_matrix        # < matrices per launch: adaptive sweep count
+                per_matrix = 16.0 * n2 ** 2                 # every matrix read + written once per launch
+                active_mats = osj_bytes / per_matrix        # < matrices per launch: adaptive sweep count, duplicates skipped
+                tfl = active_mats * flops_per_matrix_launch / (osj_us * 1e-6) / 1e12
                 tr = None
                 try:
-                    if args.workload == "c2":   # PMC passes: every matrix active in every launch -> bytes per matrix
-                        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_osj.json")))
+                    pmf = newest_profile("r*_pmc_osj.json")
+                    if args.workload in ("c2", "c4") and pmf:   # PMC passes: every matrix active in every launch -> bytes per matrix
+                        pm = json.load(open(pmf))
                         tr = pm["traffic_bytes_per_launch"] / pm["matrices_per_launch"] * active_mats
                 except Exception:
                     tr = None
+                ns = len(sketches)
                 roof = {
-                    "kernel": f"osjw_kernel<{max(1, -(-2 * ell // 64))}> (block-pair round of the one-sided Jacobi of the FD rotation, "
-                              f"{mats_per_launch:.0f} Gram matrices of order {2 * ell} per launch, "
-                              f"{len(sketches)} independent launch streams)",
-                    "bound": "hbm",
-                    "achieved": gbs,
-                    "peak": 8000.0,
-                    "unit": "GB/s",
-                    "frac": gbs / 8000.0,
+                    "kernel": f"osjw_kernel<{max(1, -(-n2 // 64))}> (block-pair round of the one-sided Jacobi of the FD rotation; fp64 "
+                              f"vector FMA, no MFMA), {mats_per_launch:.0f} Gram matrices of order {n2} per launch, "
+                              f"{ns} independent launch streams",
+                    "bound": "mfma",
+                    "achieved": tfl,
+                    "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": tfl / FP64_PEAK_TFLOPS,
                     "traffic": tr,
                     "launch_us": osj_us,
                     "launches_timed": osj_launches,
-                    "algorithmic_bytes_per_launch": osj_bytes,
+                    "executed_flops_per_launch": active_mats * flops_per_matrix_launch,
                     "matrices_active_per_launch_avg": active_mats,
-                    "concurrent_launch_streams": len(sketches),
-                    "achieved_all_streams": gbs * len(sketches),
-                    "frac_all_streams": gbs * len(sketches) / 8000.0,
-                    "note": "per-launch figures as the contract defines them; launches of the two sketch groups (and the "
-                            "adjacency / eigenstep stream) run side by side, so the kernel sustains about "
-                            "`achieved_all_streams`; `roofline_isolated` is the same kernel alone on the GPU",
+                    "concurrent_launch_streams": ns,
+                    "achieved_all_streams": tfl * ns,
+                    "frac_all_streams": tfl * ns / FP64_PEAK_TFLOPS,
+                    "note": "`bound` names the fp64 arithmetic rate (the contract's enum has no VALU entry): the kernel is "
+                            "VALU-issue bound -- 96 of ~210 vector instructions per pair-step are the FMAs counted here "
+                            "(dot products 2n + rotation 4n flop per column pair); per-launch figures, launches of the "
+                            "sketch groups run side by side (`achieved_all_streams`)",
                 }
-        # (1b) the same kernel with the GPU to itself: ONE sketch of all B lanes, nothing else running (outside the timed
-        #      region).  This is the figure that describes the kernel; (1) describes it while it shares the GPU with the
-        #      other group's launches and the adjacency / eigenstep stream.
-        roof_iso = None
-        if sketches and len(sketches) > 1 and not os.environ.get("MUSED_BENCH_NO_ISOLATED"):
-            from mused_amd.swfd import SeqBasedSWFD
-
-            torch.cuda.synchronize()
-            # every matrix of the batch a representative (no duplicate levels skipped): the launch the kernel is built for
-            prev_dd = os.environ.get("MUSED_SWFD_DEDUPE")
-            os.environ["MUSED_SWFD_DEDUPE"] = "0"
-            Bi = min(B, 9)   # 9 lanes = 1008 workgroups per launch fill two rounds of the 512 resident slots exactly
-            iso = SeqBasedSWFD(N=W, R=sketches[0].R, d=d, sketch_dim=ell, lanes=Bi)
-            if prev_dd is None:
-                del os.environ["MUSED_SWFD_DEDUPE"]
-            else:
-                os.environ["MUSED_SWFD_DEDUPE"] = prev_dd
-            iso.fit_lanes(rows_all[:Bi, 0, : 2 * ell])    # two rotations of warm-up (graph upload, clocks)
-            iso.profile(True)
-            iso.fit_lanes(rows_all[:Bi, -1, 2 * ell:])
-            ms_i, n_i, b_i = iso.profile_read()
-            iso.profile(False)
-            other_reads.append((ms_i, n_i, b_i))
-            iso.close()
-            if n_i:
-                us_i = 1e3 * ms_i / n_i
-                roof_iso = {
-                    "kernel": f"osjw_kernel<{max(1, -(-2 * ell // 64))}>, {Bi * 2 * sketches[0].L} matrices per launch (no duplicate levels skipped), one launch stream, GPU otherwise idle",
-                    "bound": "hbm", "achieved": b_i / (us_i * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": b_i / (us_i * 1e-6) / 1e9 / 8000.0, "launch_us": us_i, "launches_timed": n_i,
-                    "algorithmic_bytes_per_launch": b_i,
+                roof_hbm = {
+                    "kernel": "same launches priced on bytes: every active matrix read once and written once per launch",
+                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": tr, "launch_us": osj_us, "algorithmic_bytes_per_launch": osj_bytes,
+                    "achieved_all_streams": gbs * ns, "frac_all_streams": gbs * ns / HBM_PEAK_GBS,
                 }
         # (2) the contraction kernel: similarity GEMM X X^T on fp64 MFMA
         # SURVEY 8(d) counts 2 W d flop per row x W rows; the kernel computes the tiles on or above the diagonal only
         # (the distance / cosine epilogue is symmetric) and writes each of them twice: `achieved` is priced on the MFMA
         # work actually executed, `algorithmic_flops_per_launch` keeps the SURVEY figure
-        flops = 2.0 * W * W * d
+        d0 = dims[0]
+        flops = 2.0 * W * W * d0
         nt = -(-W // 128)
-        flops_exec = 2.0 * d * 128.0 * 128.0 * (nt * (nt + 1) // 2)
+        flops_exec = 2.0 * d0 * 128.0 * 128.0 * (nt * (nt + 1) // 2)
         gemm_ms = gemm_live_ms if gemm_live_ms else stages["scores_gemm_ms"]
         gemm_s = gemm_ms * 1e-3
         traffic = None
         try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), config 2 only
-            if args.workload == "c2":
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_scores.json")))
-                traffic = pm["traffic_bytes_per_launch_lower"]
+            pmf = newest_profile("r*_pmc_scores.json")
+            if args.workload == "c2" and pmf:
+                traffic = json.load(open(pmf))["traffic_bytes_per_launch_lower"]
         except Exception:
             traffic = None
         roof_gemm = {
@@ -492,9 +533,9 @@ def main():
                       "upper-triangular tiles + mirrored stores)",
             "bound": "mfma",
             "achieved": flops_exec / gemm_s / 1e12,
-            "peak": 78.6,
+            "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": flops_exec / gemm_s / 1e12 / 78.6,
+            "frac": flops_exec / gemm_s / 1e12 / FP64_PEAK_TFLOPS,
             "traffic": traffic,
             "launch_ms": gemm_ms,
             "launch_ms_standalone": stages["scores_gemm_ms"],
@@ -503,7 +544,7 @@ def main():
             "algorithmic_tflops_equivalent": flops / gemm_s / 1e12,
         }
         if roof is not None:
-            # every Jacobi launch of this script (warm-up windows, timed region, stand-alone stage run, isolated probe):
+            # every Jacobi launch of this script (warm-up windows, timed region, stand-alone stage run):
             # the population a `rocprofv3 --kernel-trace --stats -- python3 bench.py` average is taken over
             ms_all = osj_ms + sum(r[0] for r in other_reads)
             n_all = osj_launches + sum(r[1] for r in other_reads)
@@ -511,9 +552,33 @@ def main():
             roof["launches_whole_script"] = n_all
         if roof is None:
             roof = roof_gemm
+        value = world * K * W / elapsed
+        # (3) the whole path in SURVEY 8(d) units: algorithmic flop per row (SWFD 12 l d per FD instance, similarity
+        #     2 W d per modality, eigenstep 13 * 2 W (l + 10), dense variant) x rows/s against the fp64 peak
+        per_row = 0.0
+        if sketches:
+            per_row += 12.0 * ell * D * (2 * L_sk)
+        per_row += sum(2.0 * W * dm for dm in dims) + 13.0 * 2.0 * W * (ell + 10)
+        roof_8d = {
+            "definition": "SURVEY 8(d) algorithmic flop per row x measured rows/s of one GPU / fp64 peak",
+            "mflop_per_row": per_row / 1e6,
+            "swfd_fd_instances": 2 * L_sk if sketches else 0,
+            "achieved": per_row * (value / world) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": per_row * (value / world) / 1e12 / FP64_PEAK_TFLOPS,
+        }
+        sha16 = hashlib.sha256(all_labels.astype(np.int64).tobytes()).hexdigest()[:16]
+        golden_ok = None
+        try:   # event labels of the REFERENCE's own window loop over the same windows (tests/golden/make_golden.py)
+            gp = os.path.join(ROOT, "tests", "golden", f"bench_{args.workload}_{args.kind}_s{args.seed}.npz")
+            if os.path.exists(gp):
+                gg = np.load(gp, allow_pickle=False)
+                if world * K <= int(gg["meta"][0]):
+                    golden_ok = bool(str(gg["cumulative_sha16"][world * K - 1]) == sha16)
+        except Exception:
+            golden_ok = None
         res = {
             "metric": "stream rows/sec, d=1024 l=128 window=10k synthetic (SWFD + kNN similarity + eigenstep + labels)",
-            "value": world * K * W / elapsed,
+            "value": value,
             "unit": "rows/s",
             "n_gpus": world,
             "steps": K,
@@ -527,17 +592,25 @@ def main():
             "config": {
                 "workload": cfg["name"],
                 "stream": args.kind,
-                "W": W, "d": d, "l": ell, "k": k, "modalities": 1,
-                "swfd_levels": stages.get("swfd_levels"),
-                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {S} lock-step lane(s) per GPU",
-                "lanes_per_gpu": S,
-                "labels_sha16": __import__("hashlib").sha256(all_labels.astype(np.int64).tobytes()).hexdigest()[:16],
+                "W": W, "d": D, "l": ell, "k": k, "modalities": M,
+                "swfd_levels": L_sk,
+                "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {B} lock-step lane(s) per GPU",
+                "lanes_per_gpu": B,
+                "padded_window_slots": padded_slots,
+                "labels_sha16": sha16,
+                "labels_match_reference_golden": golden_ok,
             },
             "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
+            "single_lane": single,
+            # every lane re-sketches ONE window it does not own (its halo: SWFD MAIN(t) continues AUX(t-1)); the warm-up
+            # windows play that role here and are not timed.  On the 100-window-per-GPU stream of BASELINE config 2
+            # (1M rows) B lanes cost B extra sketch windows:
+            "value_incl_halo_100win_stream": value * 100.0 / (100.0 + B) if sketches else value,
             "stages_ms": stages,
             "roofline": roof,
-            "roofline_isolated": roof_iso,
+            "roofline_hbm": roof_hbm,
             "roofline_mfma": roof_gemm,
+            "roofline_8d": roof_8d,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.kind, args.seed, with_swfd=not args.no_swfd)

@@ -43,12 +43,14 @@ def words_for(n: int) -> int:
 
 
 def to_device_rows(data, device="cuda") -> torch.Tensor:
-    """Rows as a contiguous device tensor, keeping float32 / float64 (anything else -> float64)."""
+    """Rows as a device tensor with unit stride along the row (any row pitch: a column slice of a wider
+    resident matrix is used in place), keeping float32 / float64 (anything else -> float64)."""
     if isinstance(data, torch.Tensor):
         t = data
         if t.dtype not in (torch.float32, torch.float64):
             t = t.to(torch.float64)
-        return t.to(device).contiguous()
+        t = t.to(device)
+        return t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
     a = np.asarray(data)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64)

@@ -97,6 +97,20 @@ def array_digest(a: np.ndarray) -> str:
     return h.hexdigest()
 
 
+def stream_window_mods(window_index: int, W: int, dims, seed: int = 0, n_centres: int = 8, sep: float = 2.0):
+    """Window `window_index` of an unbounded MULTI-modality blob stream (BASELINE config 4: dims = (512, 512)): one label
+    sequence, one set of centres per modality; generated independently per window like `stream_window`.
+    Returns (rows float32 (W, sum(dims)) -- the modalities side by side --, labels int64 (W,))."""
+    base = np.random.default_rng([seed, 0x5EED, len(dims)])
+    rng = np.random.default_rng([seed, 1 + window_index, len(dims)])
+    labels = rng.integers(0, n_centres, size=W)
+    parts = []
+    for dm in dims:
+        centres = (sep * base.standard_normal((n_centres, dm))).astype(np.float32)
+        parts.append((centres[labels] + rng.standard_normal((W, dm), dtype=np.float32)).astype(np.float32))
+    return np.concatenate(parts, axis=1), labels.astype(np.int64)
+
+
 def stream_window(kind: str, window_index: int, W: int, d: int, seed: int = 0, n_centres: int = 8, sep: float = 2.0):
     """Window `window_index` of an unbounded stream, generated independently of the others (so ranks
     can materialise only their own windows).  Centres / mixing matrices depend on `seed` only; rows on

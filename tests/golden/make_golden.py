@@ -185,6 +185,34 @@ def case_stream(tag, kind, n, d, W, ell, k, seed, approach="sSVDMC", two_mod=Fal
     )
 
 
+def case_bench_stream(tag, kind, n_windows, W, d, ell, k, seed):
+    """Event labels of the reference's own window loop (main.py:13-130, approach sSVDMC) over the first `n_windows`
+    windows of the benchmark stream (mused_amd.synth.stream_window): what bench.py's `labels_sha16` is compared with.
+    Stored per window (the chain is sequential from window 0, so any prefix is a valid golden)."""
+    wins = [synth.stream_window(kind, t, W, d, seed) for t in range(n_windows)]
+    X = np.concatenate([w[0] for w in wins]).astype(np.float64)
+    labels = np.concatenate([w[1] for w in wins])
+    captured = {}
+
+    def fake_metrics(results, subset_size, noise_rate, label_mode, sorting, reduced_dim, k_basis,
+                     window_size, clusters, true_labels, t1, t0):
+        captured["clusters"] = np.asarray(clusters).copy()
+        return results
+
+    orig = ref_me.compute_all_metrics
+    ref_me.compute_all_metrics = fake_metrics
+    try:
+        quiet(ref_main.process_streaming_data, {}, [X], [""], W, ell, k, len(np.unique(labels)), seed, "sSVDMC",
+              labels, 1, 0.0, "types", False, 1.5, 2)
+    finally:
+        ref_me.compute_all_metrics = orig
+    allc = captured["clusters"].astype(np.int64).reshape(n_windows, W)
+    cum = [hashlib.sha256(allc[: t + 1].tobytes()).hexdigest()[:16] for t in range(n_windows)]
+    save(tag, meta=np.array([n_windows, W, d, ell, k, seed]), kind=np.array(kind),
+         window_digest=np.array([synth.array_digest(w[0]) for w in wins]),
+         labels=allc.astype(np.int8), cumulative_sha16=np.array(cum))
+
+
 def case_edges():
     """Small edge cases of create_adjacency_matrix / fuse / match_clusters."""
     rng = np.random.default_rng(7)
@@ -243,6 +271,8 @@ def main():
     if only:
         if "cosine" in only:
             case_cosine()
+        if "bench_c2_blob_s0" in only:   # bench.py default stream: 20 windows of BASELINE config 2
+            case_bench_stream("bench_c2_blob_s0", "blob", 20, 10000, 1024, 128, 50, 0)
         if "c3_blob_s0" in only:   # BASELINE config 3 at its real shape
             case_windows("c3_blob_s0", "blob", 10000, 4096, 10000, 256, 50, 0, n_centres=8, sep=2.0)
         if "c4_twomod_s0" in only:  # BASELINE config 4 at its real shape (one of the 8 windows)
