@@ -29,6 +29,10 @@ extern "C" {
 #define MUSED_F32 0
 #define MUSED_F64 1
 #define MUSED_I64 2
+/* mused_swfd_append* only: rows of a 0/1 matrix given as BITMASK rows (bit c of a row = element c; row pitch in
+ * 64-bit words) -- the fused adjacency of matrix_operations.py:134-141 fed to the sketch (main.py:65-67) without
+ * the dense W x W matrix ever being built */
+#define MUSED_BITS 3
 
 /* metric of the pairwise score */
 #define MUSED_METRIC_L2 0     /* squared Euclidean, matrix_operations.py:112-119 (sklearn NearestNeighbors) */

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-F32, F64, I64 = 0, 1, 2
+F32, F64, I64, BITS = 0, 1, 2, 3
 METRIC_L2, METRIC_COSINE = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

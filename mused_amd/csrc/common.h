@@ -15,6 +15,7 @@
 #define MUSED_F32 0
 #define MUSED_F64 1
 #define MUSED_I64 2
+#define MUSED_BITS 3
 
 namespace mused {
 

@@ -59,6 +59,17 @@ struct Swfd {
 static inline int sk_index(const Swfd* h, int lane, int level, int kind) { return lane * 2 * h->L + kind * h->L + level; }
 
 // ---- update ------------------------------------------------------------------------
+// Row sources: plain element rows (float / double / int64, pitch in elements) or BIT rows -- the rows of a 0/1
+// adjacency held as a bitmask (pitch in 64-bit words), which is how the reference's SWFDMC approach feeds the
+// sketch (main.py:65-67: one row of the fused W x W matrix per fit()) without the dense matrix ever existing.
+struct BitWord { unsigned long long w; };
+template <typename T>
+__device__ __forceinline__ double row_elem(const T* row, int c) { return (double)row[c]; }
+template <>
+__device__ __forceinline__ double row_elem<BitWord>(const BitWord* row, int c) {
+  return (double)((row[c >> 6].w >> (c & 63)) & 1ull);
+}
+
 template <typename T>
 __global__ void swfd_append_kernel(const T* __restrict__ X, long ldx, long lane_stride, int per_lane, int m, int d,
                                    int n2, int pend, const int* __restrict__ meta, double* __restrict__ buf) {
@@ -68,7 +79,7 @@ __global__ void swfd_append_kernel(const T* __restrict__ X, long ldx, long lane_
   if (row >= n2) return;  // cannot happen by construction (nk <= l - 1, pend + m <= l)
   double* dst = buf + ((long)s * n2 + row) * d;
   const T* src = X + (long)r * ldx;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = (double)src[c];
+  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = row_elem<T>(src, c);
 }
 
 // epoch start: MAIN <- AUX, AUX <- empty  (sketch index = kind * L + level)
@@ -298,7 +309,7 @@ __global__ void swfd_pre_load_kernel(const T* __restrict__ X, long ldx, long lan
   double* dst = out + ((long)z * ell + row) * d;
   if (row < pb.rows[blk]) {
     const T* src = X + (long)lane * lane_stride + (long)(pb.row0[blk] + row) * ldx;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = (double)src[c];
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = row_elem<T>(src, c);
   } else {
     for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = 0.0;
   }
@@ -696,8 +707,13 @@ int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, lo
 int mused_swfd_append_lanes(void* handle, const void* rows, int dtype, long n_rows, long ld, long lane_stride,
                             void* stream) {
   Swfd* h = (Swfd*)handle;
-  MUSED_REQUIRE(h && (rows || n_rows == 0) && n_rows >= 0 && ld >= h->d, "mused_swfd_append: bad arguments");
+  MUSED_REQUIRE(h && (rows || n_rows == 0) && n_rows >= 0, "mused_swfd_append: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == MUSED_BITS) {  // rows of a 0/1 matrix as bitmask rows, pitch in 64-bit words
+    MUSED_REQUIRE(ld >= (h->d + 63) / 64, "mused_swfd_append: bit rows need a pitch of at least ceil(d / 64) words");
+    return swfd_append_t<BitWord>(h, (const BitWord*)rows, ld, lane_stride, n_rows, st);
+  }
+  MUSED_REQUIRE(ld >= h->d, "mused_swfd_append: row pitch smaller than d");
   if (dtype == MUSED_F32) return swfd_append_t<float>(h, (const float*)rows, ld, lane_stride, n_rows, st);
   if (dtype == MUSED_F64) return swfd_append_t<double>(h, (const double*)rows, ld, lane_stride, n_rows, st);
   if (dtype == MUSED_I64) return swfd_append_t<long long>(h, (const long long*)rows, ld, lane_stride, n_rows, st);

@@ -119,7 +119,7 @@ class StreamPipeline:
             if self.swfd is None:  # main.py:60-62
                 R = self.eng.max_row_sq_norm(fused)
                 self.swfd = SeqBasedSWFD(N=self.W, R=R, d=fused.n, sketch_dim=self.ell)
-            self.swfd.fit(fused.to_dense())  # rows of the fused matrix, int64 for >= 2 modalities
+            self.swfd.fit_adjacency(fused)  # rows of the fused 0/1 matrix straight from the bitmask (no W x W dense)
             B, sigma, _ = self.swfd.get_device()
             reduced = B.t().contiguous() if B.shape[0] != self.W else B  # main.py:73-76
             return reduced, sigma, None

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F32, F64, I64, call
+from ._lib import BITS, F32, F64, I64, call
 from .engine import _require_gpu, ptr, stream_ptr
 
 _DT = {torch.float32: F32, torch.float64: F64, torch.int64: I64}
@@ -63,6 +63,19 @@ class SeqBasedSWFD:
             X = X.contiguous()
         call("mused_swfd_append_lanes", self._h, ptr(X), _DT[X.dtype], X.shape[1], X.stride(1), X.stride(0), stream_ptr())
         self._keepalive = X
+        return self
+
+    def fit_adjacency(self, adj):
+        """Append the rows of a device-resident 0/1 adjacency (`engine.Adjacency`, n x words bitmask) -- what the
+        reference's SWFDMC approach does row by row with the dense fused matrix (main.py:65-67); the W x W matrix is
+        never materialised: the append kernels expand bits straight into the sketch buffers."""
+        if self.lanes != 1:
+            raise ValueError("multi-lane sketch: use fit_lanes")
+        if adj.n != self.d:
+            raise ValueError(f"expected rows of length {self.d}, got {adj.n}")
+        self._flush()
+        call("mused_swfd_append", self._h, ptr(adj.mask), BITS, adj.n, adj.words, stream_ptr())
+        self._keepalive = adj.mask
         return self
 
     def fit(self, X):

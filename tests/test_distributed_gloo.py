@@ -66,12 +66,16 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_reproduce_the_reference_labels(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_reproduce_the_reference_labels(tmp_path, world):
+    """world = 2: even blocks; world = 8 over the 10 windows of the golden stream: UNEVEN blocks (2, 2, 1, 1, ...), i.e.
+    the `counts` of gather_raw_labels differ between ranks, as they will on the first real 8-GPU run."""
     from conftest import load_golden, regen_inputs
     from mused_amd import distributed as md
     from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
 
-    world = 2
+    if world == 8:
+        os.environ.setdefault("OMP_NUM_THREADS", "1")  # 8 ranks on the CPU suite's 8 cores
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     g = load_golden("c1_stream_blob_s0")
     for r in range(world):

@@ -97,6 +97,42 @@ def test_swfdmc_approach_matches_oracle_pipeline():
     assert np.array_equal(out, ref)
 
 
+def test_swfdmc_bitmask_rows_at_w2000_two_modalities():
+    """SWFDMC in the reference's wiring at a window of 2,000 rows, two modalities: the sketch is fed the rows of the
+    fused adjacency straight from the device bitmask (no dense W x W matrix), bit-identical to feeding the dense int64
+    matrix, and the event labels equal the CPU oracle pipeline's."""
+    from mused_amd import synth
+    from mused_amd.engine import WindowEngine
+    from mused_amd.pipeline import StreamPipeline
+    from mused_amd.swfd import SeqBasedSWFD
+    from oracle import mo_oracle as omo
+    from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
+
+    W, ell, k = 2000, 16, 20
+    mods, labels = synth.two_modality_blob_stream(2 * W, 24, 9, n_centres=4)
+    # (1) bit rows == dense rows, bit for bit
+    eng = WindowEngine(W)
+    fused = eng.fuse([eng.knn_adjacency(torch.from_numpy(m[:W]).cuda(), k) for m in mods])
+    R = eng.max_row_sq_norm(fused)
+    a, b = SeqBasedSWFD(N=W, R=R, d=W, sketch_dim=ell), SeqBasedSWFD(N=W, R=R, d=W, sketch_dim=ell)
+    a.fit_adjacency(fused)
+    b.fit(fused.to_dense())
+    Ba, sa, la, da = a.get()
+    Bb, sb, lb, db = b.get()
+    assert la == lb and da == db and np.array_equal(Ba, Bb) and np.array_equal(sa, sb)
+    a.close(), b.close(), eng.close()
+    # (2) whole pipeline against the oracle pipeline
+    trace = []
+    ref = omo.process_streaming_data([m.astype(np.float64) for m in mods], ["", ""], W, ell, k, 0, "SWFDMC", labels,
+                                     swfd_cls=OraSWFD, trace=trace)
+    pipe = StreamPipeline(W, ell, k, 0, "SWFDMC", async_labels=False)
+    out = pipe.run(mods, labels)
+    for x, y in zip(pipe.trace, trace):
+        np.testing.assert_allclose(x["sigma"], y["sigma"], rtol=0, atol=1e-8 * y["sigma"][0])
+    pipe.close()
+    assert np.array_equal(out, ref)
+
+
 def test_numpy_dropin_call_surface():
     """`import matrix_operations` / `from swfd import SeqBasedSWFD` via mused_amd/compat, NumPy in/out."""
     from conftest import ROOT
