@@ -137,12 +137,15 @@ def stage_profile(cfg, X, pipe, sketch, rows_grp):
     f_scores = lambda: _lib.call("mused_pairwise_scores", ptr(X0), dt, W, d0, X0.stride(0), 0, ptr(eng.norms),
                                  ptr(eng.scores), stream_ptr())
     f_scores()
-    out["scores_gemm_ms"] = hip_event_ms(f_scores, st, 3)
+    out["scores_gemm_ms"] = hip_event_ms(f_scores, st, 3)   # classic path (score matrix), for comparison
     w = (W + 63) // 64
     mask = torch.empty((W, w), dtype=torch.int64, device="cuda")
     f_sel = lambda: _lib.call("mused_select_k_smallest", ptr(eng.scores), W, W, k, None, ptr(mask), w, stream_ptr())
     f_sel()
     out["select_ms"] = hip_event_ms(f_sel, st, 3)
+    f_knn = lambda: eng.knn_adjacency(X0, k)
+    f_knn()
+    out["knn_fused_ms"] = hip_event_ms(f_knn, st, 3)   # the product path: similarity + selection, no score matrix
     adj = eng.knn_adjacency(X0, k)
     f_rsvd = lambda: eng.svd_reduce(adj, ell, pipe.seed, nnz_cap=W * k * len(cfg["dims"]))
     f_rsvd()
@@ -528,9 +531,14 @@ def main():
                 traffic = json.load(open(pmf))["traffic_bytes_per_launch_lower"]
         except Exception:
             traffic = None
+        fused_knn = pipe.eng.knn_mode != "classic"
         roof_gemm = {
-            "kernel": "gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64, "
-                      "upper-triangular tiles + mirrored stores)",
+            "kernel": ("knn_band_kernel<float> x 4 phases + cand_select_kernel (pairwise squared distances on "
+                       "v_mfma_f64_16x16x4_f64, symmetric tile grid walked by cyclic tile distance, top-k candidates "
+                       "filtered in the epilogue: no score matrix; the time covers the whole call incl. the selections)")
+            if fused_knn else
+                      ("gemm_f64_kernel<float,float,NT> + EpiSqL2 (pairwise squared distances, v_mfma_f64_16x16x4_f64, "
+                       "upper-triangular tiles + mirrored stores)"),
             "bound": "mfma",
             "achieved": flops_exec / gemm_s / 1e12,
             "peak": FP64_PEAK_TFLOPS,
@@ -538,7 +546,7 @@ def main():
             "frac": flops_exec / gemm_s / 1e12 / FP64_PEAK_TFLOPS,
             "traffic": traffic,
             "launch_ms": gemm_ms,
-            "launch_ms_standalone": stages["scores_gemm_ms"],
+            "launch_ms_standalone": stages["knn_fused_ms"] if fused_knn else stages["scores_gemm_ms"],
             "executed_flops_per_launch": flops_exec,
             "algorithmic_flops_per_launch": flops,
             "algorithmic_tflops_equivalent": flops / gemm_s / 1e12,

@@ -65,6 +65,15 @@ int mused_select_k_smallest(const double* S, long ld, int n, int k, int* out_idx
 int mused_knn_topk(const void* X, int dtype, long n, int d, long ld, int k, int metric, double* ws_scores,
                    double* ws_norms, int* out_idx, unsigned long long* out_mask, int mask_words, void* stream);
 
+/* The same selection WITHOUT the n x n score matrix: scores are filtered against a per-row running threshold as they
+ * leave the MFMA tiles (symmetric tile grid walked by cyclic tile distance, candidate lists of <= cap entries per row,
+ * exact (score, column) selection between phases).  ws: mused_knn_fused_ws_bytes(n, cap) bytes, cap <= 1024.
+ * *overflow_out (device int, written on `stream`) != 0: a row collected more than cap candidates, outputs INVALID:
+ * redo that window with mused_knn_topk. */
+long mused_knn_fused_ws_bytes(long n, int cap);
+int mused_knn_fused(const void* X, int dtype, long n, int d, long ld, int k, int metric, void* ws, long ws_bytes, int cap,
+                    int* out_idx, unsigned long long* out_mask, int mask_words, int* overflow_out, void* stream);
+
 /* ---- a3 / a4: adjacency bitmasks -------------------------------------------------------------
  * An adjacency is n rows x words uint64 (words >= ceil(n/64)); bit j of row i <=> A[i][j] = 1. */
 

@@ -32,6 +32,8 @@ _PROTOS = {
     "mused_pairwise_scores": (_i, [_vp, _i, _l, _i, _l, _i, _vp, _vp, _vp]),
     "mused_select_k_smallest": (_i, [_vp, _l, _i, _i, _vp, _vp, _i, _vp]),
     "mused_knn_topk": (_i, [_vp, _i, _l, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mused_knn_fused_ws_bytes": (_l, [_l, _i]),
+    "mused_knn_fused": (_i, [_vp, _i, _l, _i, _l, _i, _i, _vp, _l, _i, _vp, _vp, _i, _vp, _vp]),
     "mused_adj_fuse": (_i, [C.POINTER(_vp), _i, _i, _i, _vp, _vp]),
     "mused_adj_degrees": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "mused_adj_csr_fill": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

@@ -141,63 +141,19 @@ __device__ __forceinline__ int xcd_remap(int pid, int nwg) {
   return base + (pid >> 3);
 }
 
-// Epilogue concept:  void operator()(int batch, int row, int col, double v) const
-template <typename TA, typename TB, bool A_KC, bool B_KC, bool VEC, typename Epi>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+// One 128 x 128 output tile: K loop of the workgroup (staging through LDS, MFMA), result left in the accumulators.
+// C/D map of v_mfma_f64_16x16x4_f64 inside the wave's 64 x 64 block: acc[i][j][r] is the element
+//   row = wr * 64 + i * 16 + (lane >> 4) + 4 * r,   col = wc * 64 + j * 16 + (lane & 15)      (wr = wave >> 1, wc = wave & 1).
+template <typename TA, typename TB, bool A_KC, bool B_KC, bool VEC>
+__device__ __forceinline__ void gemm_tile_mainloop(const GemmArgs& g, const TA* __restrict__ A, const TB* __restrict__ B,
+                                                   int m0, int n0, int k_lo, int k_hi, double* smem,
+                                                   v4f64 (&acc)[4][4]) {
   double* As = smem;                                 // [2][BK][LD]
   double* Bs = smem + 2 * GEMM_BK * GEMM_LD;         // [2][BK][LD]
-
-  const int z = blockIdx.z;
-  if (g.rep && g.rep[z] != z) return;  // a duplicate of entry rep[z]: its consumer reads that one
-  int tm, tn;
-  if (g.sym) {
-    // C = A A^T with a symmetric epilogue: the grid holds the tiles on or above the diagonal only, row-major over
-    // the triangle (consecutive workgroups of an XCD share the A row-panel); row tm starts at
-    // e0(tm) = tm * tiles - tm (tm - 1) / 2.  Equal tile counts per XCD (a full grid with early exits gives the
-    // XCD that owns the first tile-rows twice the average work).
-    const int t = g.tiles_n, nwg = t * (t + 1) / 2;
-    const int e = xcd_remap(blockIdx.x, nwg);
-    int r = (int)((2.0 * t + 1.0 - sqrt((2.0 * t + 1.0) * (2.0 * t + 1.0) - 8.0 * e)) * 0.5);
-    r = r < 0 ? 0 : (r > t - 1 ? t - 1 : r);
-    while (r > 0 && r * t - r * (r - 1) / 2 > e) --r;
-    while (r + 1 < t && (r + 1) * t - (r + 1) * r / 2 <= e) ++r;
-    tm = r;
-    tn = r + (e - (r * t - r * (r - 1) / 2));
-  } else {
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    // grouped tile order: consecutive workgroup ids (one XCD, dispatched together) cover 8 tile-rows x 8
-    // tile-columns, so that the ~64 tiles in flight on an XCD re-use 8 A row-panels and 8 B column-panels
-    // out of its L2 instead of streaming 64 different B panels from the Infinity Cache
-    constexpr int GROUP_M = 8;
-    const int per_group = GROUP_M * g.tiles_n;
-    const int group_id = wg / per_group;
-    const int first_m = group_id * GROUP_M;
-    const int group_size = min(g.tiles_m - first_m, GROUP_M);
-    tm = first_m + (wg % group_size);
-    tn = (wg % per_group) / group_size;
-  }
-  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-  const bool mirror = g.sym && tm != tn;
-
-  int k_lo = 0, k_hi = g.K;
-  const TA* A = reinterpret_cast<const TA*>(g.A);
-  const TB* B = reinterpret_cast<const TB*>(g.B);
-  if (g.splitk) {
-    k_lo = z * g.kchunk;
-    k_hi = min(g.K, k_lo + g.kchunk);
-  } else {
-    A += (long)z * g.strideA;
-    B += (long)z * g.strideB;
-  }
-
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int kq = lane >> 4, li = lane & 15;
-
-  v4f64 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -249,6 +205,64 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
     __syncthreads();
     cur ^= 1;
   }
+}
+
+// Epilogue concept:  void operator()(int batch, int row, int col, double v) const
+template <typename TA, typename TB, bool A_KC, bool B_KC, bool VEC, typename Epi>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int z = blockIdx.z;
+  if (g.rep && g.rep[z] != z) return;  // a duplicate of entry rep[z]: its consumer reads that one
+  int tm, tn;
+  if (g.sym) {
+    // C = A A^T with a symmetric epilogue: the grid holds the tiles on or above the diagonal only, row-major over
+    // the triangle (consecutive workgroups of an XCD share the A row-panel); row tm starts at
+    // e0(tm) = tm * tiles - tm (tm - 1) / 2.  Equal tile counts per XCD (a full grid with early exits gives the
+    // XCD that owns the first tile-rows twice the average work).
+    const int t = g.tiles_n, nwg = t * (t + 1) / 2;
+    const int e = xcd_remap(blockIdx.x, nwg);
+    int r = (int)((2.0 * t + 1.0 - sqrt((2.0 * t + 1.0) * (2.0 * t + 1.0) - 8.0 * e)) * 0.5);
+    r = r < 0 ? 0 : (r > t - 1 ? t - 1 : r);
+    while (r > 0 && r * t - r * (r - 1) / 2 > e) --r;
+    while (r + 1 < t && (r + 1) * t - (r + 1) * r / 2 <= e) ++r;
+    tm = r;
+    tn = r + (e - (r * t - r * (r - 1) / 2));
+  } else {
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    // grouped tile order: consecutive workgroup ids (one XCD, dispatched together) cover 8 tile-rows x 8
+    // tile-columns, so that the ~64 tiles in flight on an XCD re-use 8 A row-panels and 8 B column-panels
+    // out of its L2 instead of streaming 64 different B panels from the Infinity Cache
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int group_id = wg / per_group;
+    const int first_m = group_id * GROUP_M;
+    const int group_size = min(g.tiles_m - first_m, GROUP_M);
+    tm = first_m + (wg % group_size);
+    tn = (wg % per_group) / group_size;
+  }
+  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+  const bool mirror = g.sym && tm != tn;
+
+  int k_lo = 0, k_hi = g.K;
+  const TA* A = reinterpret_cast<const TA*>(g.A);
+  const TB* B = reinterpret_cast<const TB*>(g.B);
+  if (g.splitk) {
+    k_lo = z * g.kchunk;
+    k_hi = min(g.K, k_lo + g.kchunk);
+  } else {
+    A += (long)z * g.strideA;
+    B += (long)z * g.strideB;
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kq = lane >> 4, li = lane & 15;
+
+  v4f64 acc[4][4];
+  gemm_tile_mainloop<TA, TB, A_KC, B_KC, VEC>(g, A, B, m0, n0, k_lo, k_hi, smem, acc);
 
   // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll

@@ -50,6 +50,12 @@ __global__ void inv_norm_kernel(const double* __restrict__ sq, long n, double* _
   inv[i] = (nr == 0.0) ? 1.0 : 1.0 / nr;  // sklearn normalize(): zero norms replaced by 1
 }
 
+int inv_norms_launch(double* norms, long n, hipStream_t st) {
+  hipLaunchKernelGGL(inv_norm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, norms, n, norms);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
 // ---- epilogues ---------------------------------------------------------------
 struct EpiSqL2 {
   double* S;
@@ -72,7 +78,9 @@ struct EpiNegCos {
   __device__ __forceinline__ void operator()(int, int row, int col, double v) const {
     S[(long)row * ld + col] = value(row, col, v);
   }
-  __device__ __forceinline__ double value(int row, int col, double v) const { return -(v * inv[row] * inv[col]); }
+  // 0.0 - x, not -x: a zero dot product gives +0.0 whatever its sign, so that equal similarities are equal KEYS for the
+  // selection too (ties then go to the smaller column, as everywhere else)
+  __device__ __forceinline__ double value(int row, int col, double v) const { return 0.0 - (v * inv[row] * inv[col]); }
   __device__ __forceinline__ void put(int, int row, int col, double val) const { S[(long)row * ld + col] = val; }
 };
 

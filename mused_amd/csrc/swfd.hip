@@ -23,7 +23,7 @@
 namespace mused {
 
 struct Swfd {
-  int N, d, ell, L, S, cap, n2, n4;
+  int N, d, ell, L, S, cap, n2, n4, n3;
   int lanes;  // independent sketch sets advanced in lockstep (S = lanes * 2L sketches in every launch)
   double R;
   long i;    // rows seen so far
@@ -49,6 +49,7 @@ struct Swfd {
   double *stack, *evals_q, *Uq, *Wq, *Bout, *sig_out, *qinfo;
   int* qsel;  // {level, nsnap, nk, slots[cap]}
   EigPlan* eigq;
+  EigPlan* eigq3;  // order n3 = 3l (even): enough whenever nothing is pending (snapshots <= 2l, kept rows <= l - 1)
   // pre-rotation of complete l-row input blocks (see swfd_prerotate)
   int pre_chunk;        // blocks per batch (0: off)
   double *pre_in, *pre_out, *pre_gram;  // [chunk][lanes][l][d] fp64 rows in / out, [chunk][lanes][l][l] Gram matrices
@@ -535,19 +536,23 @@ __global__ __launch_bounds__(256) void swfd_finish_rows_kernel(double* __restric
 }
 
 static int swfd_query(Swfd* h, double* outB, double* outSigma, double* outInfo, hipStream_t st) {
-  const int n4 = h->n4, d = h->d, ell = h->ell, B = h->lanes;
+  // stacked rows = in-window snapshots (<= 2l) + kept rows (<= l - 1) + pending rows: a query on a rotation boundary
+  // (every window boundary is one) has nothing pending and fits order 3l -- 0.42 of the eigenwork of order 4l
+  const bool small = (h->pend == 0) && h->eigq3;
+  EigPlan* const eq = small ? h->eigq3 : h->eigq;
+  const int n4 = small ? h->n3 : h->n4, d = h->d, ell = h->ell, B = h->lanes;
   int rc;
   hipLaunchKernelGGL(swfd_select_kernel, dim3(B), dim3(64), 0, st, h->meta, h->qt, h->dropped, h->L, h->cap, h->N,
                      (long long)h->i, h->qsel);
   hipLaunchKernelGGL(swfd_stack_kernel, dim3(n4, B), dim3(256), 0, st, h->qsel, h->buf, h->queue, h->n2, n4, h->cap, d,
                      h->pend, h->stack);
-  if ((rc = gemm_f64(true, true, h->stack, d, (long)n4 * d, h->stack, d, (long)n4 * d, eig_plan_input(h->eigq), n4,
+  if ((rc = gemm_f64(true, true, h->stack, d, (long)n4 * d, h->stack, d, (long)n4 * d, eig_plan_input(eq), n4,
                      (long)n4 * n4, n4, n4, d, B, 1.0, st)))
     return rc;
   const double *ecols = nullptr, *elam = nullptr;
   int eld = 0;
-  const bool raw = eig_plan_columns(h->eigq, &ecols, &elam, &eld);
-  if ((rc = eig_plan_run_inplace(h->eigq, raw ? nullptr : h->evals_q, raw ? nullptr : h->Uq, st, true))) return rc;
+  const bool raw = eig_plan_columns(eq, &ecols, &elam, &eld);
+  if ((rc = eig_plan_run_inplace(eq, raw ? nullptr : h->evals_q, raw ? nullptr : h->Uq, st, true))) return rc;
   hipLaunchKernelGGL(swfd_decide_query_kernel, dim3(B), dim3(1024), 0, st, raw ? elam : h->evals_q, raw ? ecols : h->Uq,
                      raw ? eld : n4, raw ? 1 : 0, n4, ell, h->cap, h->qsel,
                      h->Wq, h->qinfo);
@@ -600,6 +605,7 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   h->cap = 2 * ell;
   h->n2 = 2 * ell;
   h->n4 = 4 * ell;
+  h->n3 = (3 * ell + 1) & ~1;
   // cap of the adaptive sweep count: full-rank buffers stop after 10-11 sweeps, dense rank-deficient Gram
   // matrices (d < 2l, or linearly dependent rows) need up to 20 to push the null-space columns below the drop tolerance
   h->sweeps = sweeps > 0 ? sweeps : 24;
@@ -635,6 +641,7 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   if ((rc = gemm_f64_prepare_all())) return rc;
   if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep))) return rc;
   if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq))) return rc;
+  if (h->n3 < h->n4 && (rc = eig_plan_create(h->n3, lanes, h->sweeps + 2, true, &h->eigq3))) return rc;
   {
     // input-block pre-rotation (swfd_prerotate): batches of `pre_chunk` blocks x lanes, workspace <= ~256 MB per array
     const char* pr = getenv("MUSED_SWFD_PREROT");
@@ -664,6 +671,7 @@ int mused_swfd_destroy(void* handle) {
   if (!h) return MUSED_OK;
   eig_plan_destroy(h->eig);
   eig_plan_destroy(h->eigq);
+  if (h->eigq3) eig_plan_destroy(h->eigq3);
   if (h->eigp) eig_plan_destroy(h->eigp);
   void* bufs[] = {h->buf, h->queue, h->qt, h->meta, h->dropped, h->theta, h->T, h->Wc, h->evals, h->U, h->plan,
                   h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel,

@@ -2,10 +2,12 @@
 
 One `WindowEngine` owns the persistent HBM workspaces for windows of up to `n_max` rows:
 
-    scores   n x n  fp64   pairwise scores of the current modality      (8 n^2 B, 800 MB at n = 10^4)
-    norms    n      fp64
+    knn_ws   candidate lists of the fused similarity / top-k kernels: n x cap (score, column) + thresholds
+             (85 MB at n = 10^4, cap = 704; mused_amd/csrc/knn_fused.hip).  No n x n score matrix.
     masks    per-modality and fused adjacency BITMASKS, n x ceil(n/64) uint64 (12.5 MB at n = 10^4)
     rsvd     handle of the randomized-SVD eigenstep (CSR lists, n x (l+10) panels, hipGraph)
+    scores   n x n fp64 (800 MB at n = 10^4): allocated ONLY if the classic path is asked for (MUSED_KNN=classic,
+             unit tests of the primitives) or a window overflows the candidate lists (pathological inputs)
 
 Nothing W x W and dense ever leaves the device unless the NumPy-compatible wrappers in
 `mused_amd.matrix_operations` ask for it.  torch is used for device memory and streams only;
@@ -14,6 +16,7 @@ all arithmetic is in libmused_hip (ctypes, raw pointers).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -131,8 +134,13 @@ class WindowEngine:
         _require_gpu()
         self.n_max = int(n_max)
         self.device = device
-        self.scores = torch.empty(self.n_max * self.n_max, dtype=torch.float64, device=device)
+        self._scores = None  # classic path only, allocated on first use
         self.norms = torch.empty(self.n_max, dtype=torch.float64, device=device)
+        self.knn_mode = os.environ.get("MUSED_KNN", "fused")
+        self._knn_ws = None
+        self._knn_cap = 0
+        self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
+        self.knn_fallbacks = 0  # windows redone on the classic path because a candidate list overflowed
         self._rsvd = None
         self._rsvd_key = None
         self._rsvd_cap = 0
@@ -140,6 +148,25 @@ class WindowEngine:
         # optional live timing: set to a list and every score-GEMM launch is bracketed by HIP events
         # recorded on the launch stream -> [(start_event, end_event), ...]
         self.score_events = None
+
+    @property
+    def scores(self) -> torch.Tensor:
+        """n_max x n_max fp64 score workspace of the CLASSIC path (mused_pairwise_scores + mused_select_k_smallest)."""
+        if self._scores is None:
+            self._scores = torch.empty(self.n_max * self.n_max, dtype=torch.float64, device=self.device)
+        return self._scores
+
+    def _fused_ws(self, kk: int):
+        # a phase admits about twice the k candidates already held (it shows twice the columns seen so far): 4 k + 128
+        # leaves a margin of two; beyond 1024 per row (k > 224) the classic path is used instead
+        cap = max(704, ((4 * kk + 128 + 63) // 64) * 64)  # 704: room for the 5 x 128 scores of the first phase
+        if int(os.environ.get("MUSED_KNN_CAP", "0")) > 0:
+            cap = int(os.environ["MUSED_KNN_CAP"])
+        if self._knn_ws is None or self._knn_cap != cap:
+            nbytes = int(_lib.lib().mused_knn_fused_ws_bytes(self.n_max, cap))
+            self._knn_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._knn_cap = cap
+        return self._knn_ws, cap
 
     # ---- a1 / a2 ------------------------------------------------------------------------
     def knn_adjacency(self, rows, k: int, metric: str = "l2", want_idx: bool = False):
@@ -168,13 +195,29 @@ class WindowEngine:
         if self.score_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        call("mused_pairwise_scores", ptr(X), _DT[X.dtype], n, d, X.stride(0), m, ptr(self.norms), ptr(self.scores),
-             stream_ptr())
-        if self.score_events is not None:
-            e1.record()
-            self.score_events.append((e0, e1))
-        call("mused_select_k_smallest", ptr(self.scores), n, n, kk, ptr(idx) if want_idx else None, ptr(mask), w,
-             stream_ptr())
+        fused = self.knn_mode != "classic" and 4 * kk + 128 <= 1024
+        if fused:
+            ws, cap = self._fused_ws(kk)
+            fused = kk <= cap <= 1024
+        if fused:
+            # similarity + selection in one pass over the tiles, no n x n score matrix (knn_fused.hip)
+            call("mused_knn_fused", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(ws), ws.numel(), cap,
+                 ptr(idx) if want_idx else None, ptr(mask), w, ptr(self._ovf), stream_ptr())
+            if self.score_events is not None:
+                e1.record()
+                self.score_events.append((e0, e1))
+            # one small host read per modality and window: the host stays at most one stage ahead of the device
+            if int(self._ovf.item()) != 0:
+                self.knn_fallbacks += 1
+                fused = False
+        if not fused:
+            call("mused_pairwise_scores", ptr(X), _DT[X.dtype], n, d, X.stride(0), m, ptr(self.norms), ptr(self.scores),
+                 stream_ptr())
+            if self.score_events is not None and self.knn_mode == "classic":
+                e1.record()
+                self.score_events.append((e0, e1))
+            call("mused_select_k_smallest", ptr(self.scores), n, n, kk, ptr(idx) if want_idx else None, ptr(mask), w,
+                 stream_ptr())
         adj = Adjacency(mask, n)
         return (adj, idx) if want_idx else adj
 

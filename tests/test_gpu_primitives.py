@@ -381,3 +381,139 @@ def test_fd_rotate(L, ell, d):
         sgn = np.sign(out[i] @ ref[i]) or 1.0
         np.testing.assert_allclose(sgn * out[i], ref[i], atol=1e-7 * s[0])
     np.testing.assert_allclose(out.T @ out, ref.T @ ref, atol=1e-9 * s[0] ** 2)
+
+
+# ---------------------------------------------------------------- fused similarity + top-k (no n x n matrix) ----
+def _classic_topk(L, X, k, metric):
+    n, d = X.shape
+    dX = dev(X)
+    ws = torch.empty(n * n, dtype=torch.float64, device="cuda")
+    nr = torch.empty(n, dtype=torch.float64, device="cuda")
+    w = (n + 63) // 64
+    idx = torch.empty((n, k), dtype=torch.int32, device="cuda")
+    mask = torch.empty((n, w), dtype=torch.int64, device="cuda")
+    dt = 0 if X.dtype == np.float32 else 1
+    L.call("mused_knn_topk", P(dX), dt, n, d, d, k, metric, P(ws), P(nr), P(idx), P(mask), w, S())
+    sync()
+    return idx.cpu().numpy(), mask.cpu().numpy()
+
+
+def _fused_topk(L, X, k, metric, cap):
+    n, d = X.shape
+    dX = dev(X)
+    nb = L.lib().mused_knn_fused_ws_bytes(n, cap)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    w = (n + 63) // 64 + 1  # a pitch larger than needed: the extra word must come out zero
+    idx = torch.full((n, k), -1, dtype=torch.int32, device="cuda")
+    mask = torch.full((n, w), -1, dtype=torch.int64, device="cuda")
+    ovf = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    dt = 0 if X.dtype == np.float32 else 1
+    L.call("mused_knn_fused", P(dX), dt, n, d, d, k, metric, P(ws), nb, cap, P(idx), P(mask), w, P(ovf), S())
+    sync()
+    return idx.cpu().numpy(), mask.cpu().numpy(), int(ovf.item())
+
+
+@pytest.mark.parametrize("n,d,k,metric,dtype", [
+    (100, 9, 7, 0, np.float64),       # one tile
+    (128, 16, 128, 0, np.float32),    # k = n
+    (300, 33, 20, 0, np.float32),     # 3 tiles, ragged last tile, unaligned rows (scalar loads)
+    (1024, 64, 50, 0, np.float32),    # 8 tiles: even tile count (antipodal pairs once)
+    (1500, 48, 50, 1, np.float32),    # cosine, 12 tiles
+    (2000, 24, 200, 0, np.float64),   # large k: the lists hold 4 k + 128 candidates
+    (2900, 40, 31, 1, np.float64),    # 23 tiles: four phases
+])
+def test_knn_fused_equals_classic(L, n, d, k, metric, dtype):
+    """Fused similarity + selection (no score matrix) == mused_pairwise_scores + mused_select_k_smallest, bit for bit:
+    neighbour lists (ascending columns) and adjacency bitmask rows."""
+    rng = np.random.default_rng(n + d + k)
+    X = rng.standard_normal((n, d)).astype(dtype)
+    X[n // 3] = X[n // 5]          # duplicate rows: exact score ties across tiles
+    if metric == 0 or n <= 1500:
+        X[n // 2] = 0.0            # a zero row (cosine: norm replaced by 1, every score of the row equal)
+    # (a row of all-equal scores admits every column smaller than its current k-th one: in a long window that overflows
+    # the lists and the engine falls back to the classic path -- test_engine_cosine_zero_rows_fall_back below)
+    cap = 1024
+    i_ref, m_ref = _classic_topk(L, X, k, metric)
+    i_fu, m_fu, ovf = _fused_topk(L, X, k, metric, cap)
+    assert ovf == 0
+    assert np.array_equal(i_fu, i_ref)
+    w = (n + 63) // 64
+    assert np.array_equal(m_fu[:, :w], m_ref) and not m_fu[:, w:].any()
+
+
+def test_knn_fused_ties_and_overflow_flag(L):
+    """Lattice data (thousands of exactly equal scores): with room in the lists the result equals the classic path,
+    with a tight cap the overflow flag is raised (the engine then falls back to the classic path)."""
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 2, size=(700, 6)).astype(np.float64)   # 64 distinct points, ~11 copies each
+    i_ref, m_ref = _classic_topk(L, X, 30, 0)
+    i_fu, m_fu, ovf = _fused_topk(L, X, 30, 0, 1024)
+    assert ovf == 0 and np.array_equal(i_fu, i_ref) and np.array_equal(m_fu[:, :11], m_ref)
+    _, _, ovf = _fused_topk(L, X, 30, 0, 64)
+    assert ovf != 0
+
+
+def test_engine_falls_back_when_candidate_lists_overflow(L, monkeypatch):
+    from mused_amd.engine import WindowEngine
+    from oracle import mo_oracle as omo
+
+    rng = np.random.default_rng(6)
+    X = rng.integers(0, 2, size=(640, 5)).astype(np.float64)
+    monkeypatch.setenv("MUSED_KNN_CAP", "64")
+    eng = WindowEngine(640)
+    adj = eng.knn_adjacency(torch.from_numpy(X).cuda(), 25)
+    assert eng.knn_fallbacks == 1 and eng._scores is not None
+    bits = np.unpackbits(adj.mask.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :640].astype(bool)
+    assert np.array_equal(bits, omo.create_adjacency_matrix(X, "", 25).astype(bool))
+    eng.close()
+
+
+def test_engine_cosine_zero_rows_fall_back(L):
+    """Zero-norm rows under cosine have the same similarity (0) to every row: thousands of exact ties.  Whether the
+    candidate lists overflow or not, the adjacency equals the oracle's (ties to the smaller column)."""
+    from mused_amd.engine import WindowEngine
+    from oracle import mo_oracle as omo
+
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((2900, 24))
+    X[::97] = 0.0
+    eng = WindowEngine(2900)
+    adj = eng.knn_adjacency(torch.from_numpy(X).cuda(), 31, "cosine")
+    bits = np.unpackbits(adj.mask.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :2900].astype(bool)
+    assert np.array_equal(bits, omo.create_adjacency_matrix(X, "cosine", 31).astype(bool))
+    eng.close()
+
+
+def test_engine_uses_the_classic_path_for_very_large_k(L):
+    """k > 224 does not fit the candidate lists (4 k + 128 <= 1024): the engine takes the score-matrix path."""
+    from mused_amd.engine import WindowEngine
+    from oracle import mo_oracle as omo
+
+    X = np.random.default_rng(8).standard_normal((900, 12))
+    eng = WindowEngine(900)
+    adj = eng.knn_adjacency(torch.from_numpy(X).cuda(), 500)
+    assert eng._scores is not None and eng.knn_fallbacks == 0
+    bits = np.unpackbits(adj.mask.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :900].astype(bool)
+    assert np.array_equal(bits, omo.create_adjacency_matrix(X, "", 500).astype(bool))
+    eng.close()
+
+
+def test_engine_default_path_allocates_no_score_matrix(L):
+    """W = 10,000: the product path keeps < 100 MB of similarity workspace (the classic path needs 800 MB)."""
+    from mused_amd import synth
+    from mused_amd.engine import WindowEngine
+
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    before = torch.cuda.memory_allocated()
+    eng = WindowEngine(10000)
+    X = torch.from_numpy(synth.stream_window("blob", 3, 10000, 256, 0)[0]).cuda()
+    base = torch.cuda.memory_allocated()
+    adj = eng.knn_adjacency(X, 50)
+    torch.cuda.synchronize()
+    assert eng._scores is None and eng.knn_fallbacks == 0
+    assert eng._knn_ws.numel() < 100e6                      # candidate lists + thresholds
+    assert torch.cuda.memory_allocated() - base < 128e6     # ... plus the adjacency bitmask it returns
+    assert int(adj.degrees()[2][0].item()) == 49
+    eng.close()
+    (before,)
