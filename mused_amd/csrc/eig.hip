@@ -19,6 +19,13 @@
 
 namespace mused {
 
+struct OsjqCtl {
+  unsigned head, tail;  // tickets handed to consumers / slots handed to producers
+  int finished, nmat;   // matrices whose solve has ended / matrices that take part (representatives)
+  int all_done, error;  // set once: nothing will ever be queued again / a consumer gave up waiting (timeout)
+  int pad[2];
+};
+
 struct EigPlan {
   int n, batch, sweeps;
   int method;  // 0 = two-sided, one launch per rotation set; 1 = one-sided block Jacobi (default)
@@ -31,6 +38,12 @@ struct EigPlan {
   const int* rep; // optional: matrix b is a duplicate of matrix rep[b] != b and is not solved
   int sortcols;  // OSJ: store columns by descending norm inside each block pair
   int sort_from; // OSJ wave kernel: first sweep that sorts
+  // persistent work-queue solver (orders <= 256, see osjq_kernel): one launch per solve instead of sweeps x (nb - 1)
+  int use_queue;
+  unsigned* q;        // unit ring: 0 = empty, else 1 + ((matrix * 256 + global round) * 4 + block pair)
+  unsigned qcap;
+  struct OsjqCtl* qctl;
+  int* qdone;         // per matrix: units of its current round that have finished
   double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv / work point into)
   unsigned long long* work;  // OSJ adaptive, profiling: (matrix, sweep) pairs that did work
   // live profiling (off by default): HIP events around every replay of the sweep graph
@@ -715,33 +728,44 @@ __device__ __forceinline__ void osjw_deal(double (&x)[2 * SC * RP], OsjwShared<R
   __syncthreads();  // everyone has taken its set: the buffers may be written again
 }
 
-template <int RP, int SC, bool PREFIX>
-__global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb,
-                                                                                  int round,
-                                                                                  int* __restrict__ notconv, int sweep,
-                                                                                  const double* __restrict__ trace,
-                                                                                  int sortcols,
-                                                                                  const int* __restrict__ rep) {
-  if (rep && rep[blockIdx.y] != (int)blockIdx.y) return;  // duplicate of another matrix of the batch
-  static_assert(!PREFIX || SC == 8, "the in-launch intra-block schedule exists for 8-column sets only");
-  if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
-  double small2 = notconv ? 0.0 : -1.0;
-  if (trace) {
-    const double tr = trace[blockIdx.y];
-    small2 = 1e-24 * tr * tr;
+// Loads / stores of the matrix columns.  COH = false: plain accesses (the kernel boundary publishes them).  COH = true:
+// agent-scope relaxed atomics = global_load / global_store ... sc1 -- every byte another workgroup of the SAME launch
+// wrote is read past this CU's L1 and every byte it will read is written through (persistent solver below).
+template <bool COH>
+__device__ __forceinline__ double osj_ld(const double* p) {
+  if constexpr (COH) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else {
+    return *p;
   }
+}
+template <bool COH>
+__device__ __forceinline__ void osj_st(double* p, double v) {
+  if constexpr (COH) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+
+// One block-pair round of one matrix by one workgroup (the body of osjw_kernel): returns (per wave) whether a pair that
+// still matters was met.  kidx = index of the block pair in the round-robin of `round`.
+template <int RP, int SC, bool PREFIX, bool COH>
+__device__ __forceinline__ int osjw_unit(double* __restrict__ M, int ldn, int nb, int round, int kidx, double small2,
+                                         int sortcols, OsjwShared<RP, SC>& sh, int tid) {
+  static_assert(!PREFIX || SC == 8, "the in-launch intra-block schedule exists for 8-column sets only");
   constexpr int CB = OSJ_CB, NW = OSJ_CB / SC;
-  __shared__ OsjwShared<RP, SC> sh;
-  double* M = Gc + (long)blockIdx.y * ldn * ldn;
   int bp, bq;
   {
-    const int k = blockIdx.x, m = nb - 1;
+    const int k = kidx, m = nb - 1;
     const int a = (k == 0) ? m : (round + k) % m;
     const int b = (k == 0) ? (round % m) : ((round - k + m) % m);
     bp = a < b ? a : b;
     bq = a < b ? b : a;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   // sets 0 .. NW-1 = columns of block bp, NW .. 2NW-1 = block bq
   int ida = PREFIX ? 2 * wave : wave, idb = PREFIX ? 2 * wave + 1 : NW + wave;
   auto set_col = [&](int sid) { return (sid < NW ? bp * CB + SC * sid : bq * CB + SC * (sid - NW)); };
@@ -752,8 +776,8 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
     for (int j = 0; j < SC; ++j)
 #pragma unroll
       for (int i = 0; i < RP; ++i) {
-        x[j * RP + i] = M[(long)(ca + j) * ldn + lane + 64 * i];
-        x[(SC + j) * RP + i] = M[(long)(cb + j) * ldn + lane + 64 * i];
+        x[j * RP + i] = osj_ld<COH>(&M[(long)(ca + j) * ldn + lane + 64 * i]);
+        x[(SC + j) * RP + i] = osj_ld<COH>(&M[(long)(cb + j) * ldn + lane + 64 * i]);
       }
   }
   {  // squared norms of the wave's 2 SC columns
@@ -815,7 +839,7 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
       const int colg = (pos < CB) ? (bp * CB + pos) : (bq * CB + pos - CB);
       const double dd = sh.dsc[wave][c];
 #pragma unroll
-      for (int i = 0; i < RP; ++i) M[(long)colg * ldn + lane + 64 * i] = x[c * RP + i] * dd;
+      for (int i = 0; i < RP; ++i) osj_st<COH>(&M[(long)colg * ldn + lane + 64 * i], x[c * RP + i] * dd);
     }
   } else {
     const int ca = set_col(ida), cb = set_col(idb);
@@ -824,12 +848,167 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
       const double da = sh.dsc[wave][j], db = sh.dsc[wave][SC + j];
 #pragma unroll
       for (int i = 0; i < RP; ++i) {
-        M[(long)(ca + j) * ldn + lane + 64 * i] = x[j * RP + i] * da;
-        M[(long)(cb + j) * ldn + lane + 64 * i] = x[(SC + j) * RP + i] * db;
+        osj_st<COH>(&M[(long)(ca + j) * ldn + lane + 64 * i], x[j * RP + i] * da);
+        osj_st<COH>(&M[(long)(cb + j) * ldn + lane + 64 * i], x[(SC + j) * RP + i] * db);
       }
     }
   }
-  if (notconv && __any(active) && lane == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
+  return active;
+}
+
+template <int RP, int SC, bool PREFIX>
+__global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb,
+                                                                                  int round,
+                                                                                  int* __restrict__ notconv, int sweep,
+                                                                                  const double* __restrict__ trace,
+                                                                                  int sortcols,
+                                                                                  const int* __restrict__ rep) {
+  if (rep && rep[blockIdx.y] != (int)blockIdx.y) return;  // duplicate of another matrix of the batch
+  if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
+  double small2 = notconv ? 0.0 : -1.0;
+  if (trace) {
+    const double tr = trace[blockIdx.y];
+    small2 = 1e-24 * tr * tr;
+  }
+  __shared__ OsjwShared<RP, SC> sh;
+  double* M = Gc + (long)blockIdx.y * ldn * ldn;
+  const int active = osjw_unit<RP, SC, PREFIX, false>(M, ldn, nb, round, blockIdx.x, small2, sortcols, sh, threadIdx.x);
+  if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
+}
+
+// ---- persistent work-queue solver (orders <= 256) ---------------------------------------------------------------
+// The launch-per-round solver above pays, per block-pair round, a kernel boundary whose length is set by the slowest
+// matrix of the batch, and runs as many rounds as the slowest matrix needs sweeps.  Here ONE launch solves the whole
+// batch: a UNIT of work is the same block-pair round of one matrix (osjw_unit), units are handed out through a ticket
+// queue in global memory, and a matrix advances on its own -- the workgroup that finishes the last unit of a matrix's
+// round r queues the units of round r + 1 (or ends the matrix: converged / sweep cap).  Matrices that converge early
+// stop costing anything and the workgroup slots stay busy until the batch is done.
+//   * No workgroup ever waits for a particular other workgroup to be resident: a consumer holding ticket t waits for
+//     slot t of the queue, which is filled by whichever workgroup completes the round that produces it -- and every
+//     such round consists of units already handed to running workgroups.  Any number of resident workgroups >= 1 makes
+//     progress, so the kernel cannot deadlock on co-residency (MI355X_MICROARCH: dispatch order is not a contract).
+//   * Visibility between workgroups (per-XCD L2s are not coherent, a CU's L1 is never refreshed): every byte of the
+//     matrices is written by sc1 write-through stores and read by sc1 loads (osj_ld / osj_st<true>); a unit's waves drain
+//     their stores (s_waitcnt vmcnt(0)), meet at the workgroup barrier, then ONE lane counts the unit in with an
+//     agent-scope atomic; queue slots, counters and flags are agent-scope atomics throughout.
+//   * Every spin is bounded (s_memrealtime): on a timeout the error word is set and every workgroup leaves.
+// Arithmetic and order of operations per matrix are those of the launch-per-round solver: results are bit-identical.
+constexpr unsigned OSJQ_EXIT = 0xffffffffu;
+
+__global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict__ q, int* __restrict__ qdone, int batch,
+                                 int upr, const int* __restrict__ rep) {
+  // (q has been zeroed by the launch before)
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m == 0) {
+    ctl->head = 0; ctl->finished = 0; ctl->all_done = 0; ctl->error = 0;
+  }
+  if (m >= batch) return;
+  qdone[m] = 0;
+  if (rep && rep[m] != m) return;
+  const unsigned pos = atomicAdd(&ctl->tail, (unsigned)upr);
+  for (int i = 0; i < upr; ++i) q[pos + i] = 1u + (((unsigned)m * 256u + 0u) * 4u + (unsigned)i);
+  atomicAdd(&ctl->nmat, 1);
+}
+
+__global__ void osjq_reset_kernel(OsjqCtl* __restrict__ ctl) { ctl->tail = 0; ctl->nmat = 0; }
+
+template <int RP>
+__global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, int ldn, int nb, int batch, int max_sweeps,
+                                                     int sort_from, int* __restrict__ notconv,
+                                                     const double* __restrict__ trace, unsigned* __restrict__ q,
+                                                     unsigned qcap, OsjqCtl* __restrict__ ctl, int* __restrict__ qdone) {
+  __shared__ OsjwShared<RP, 8> sh;
+  __shared__ unsigned s_item;
+  const int rounds = nb - 1, upr = nb / 2;
+  while (true) {
+    if (threadIdx.x == 0) {
+      unsigned item = OSJQ_EXIT;
+      const unsigned t = atomicAdd(&ctl->head, 1u);
+      if (t < qcap) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        while ((item = __hip_atomic_load(&q[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+          if (__hip_atomic_load(&ctl->all_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            item = OSJQ_EXIT;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {  // 3 s: give up, tell everyone
+            __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item = OSJQ_EXIT;
+            break;
+          }
+        }
+      }
+      s_item = item;
+    }
+    __syncthreads();
+    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)s_item);  // wave-uniform: lives in SGPRs
+    __syncthreads();  // s_item is rewritten by the next round of the loop
+    if (item == OSJQ_EXIT) return;
+    const unsigned v = item - 1u;
+    const int k = (int)(v & 3u), R = (int)((v >> 2) & 255u), m = (int)(v >> 10);
+    const int sweep = R / rounds, r = R - sweep * rounds;
+    double small2 = notconv ? 0.0 : -1.0;
+    if (trace) {
+      const double tr = trace[m];
+      small2 = 1e-24 * tr * tr;
+    }
+    double* M = Gc + (long)m * ldn * ldn;
+    const int so = sweep >= sort_from ? 1 : 0;
+    int active;
+    // the thread index is made opaque per unit: otherwise every lane-dependent LDS / global address of the unit is a
+    // loop invariant of the persistent loop, gets hoisted out of it and is kept (and spilled) across the whole unit
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    if (r == 0) active = osjw_unit<RP, 8, true, true>(M, ldn, nb, 0, k, small2, so, sh, tid);
+    else active = osjw_unit<RP, 8, false, true>(M, ldn, nb, r, k, small2, so, sh, tid);
+    if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[sweep * batch + m], 1);
+    // publish: every wave drains its write-through stores (and its flag atomic) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ... all of them have; LDS of this unit is free again
+    if (threadIdx.x == 0) {  // ... then ONE lane counts the unit in
+      const int old = atomicAdd(&qdone[m], 1);
+      if (old == upr - 1) {  // last unit of round R of matrix m: nobody else touches this matrix now
+        __hip_atomic_store(&qdone[m], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool fin = false;
+        if (r == rounds - 1) {
+          fin = sweep + 1 >= max_sweeps;
+          if (notconv && !fin)
+            fin = __hip_atomic_load(&notconv[sweep * batch + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        }
+        if (fin) {
+          const int f = atomicAdd(&ctl->finished, 1);
+          if (f + 1 == ctl->nmat) __hip_atomic_store(&ctl->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counter reset is out before the units that count on it
+          const unsigned tt = atomicAdd(&ctl->tail, (unsigned)upr);
+          for (int i = 0; i < upr; ++i)
+            if (tt + i < qcap)
+              __hip_atomic_store(&q[tt + i], 1u + (((unsigned)m * 256u + (unsigned)(R + 1)) * 4u + (unsigned)i),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+}
+
+__global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) q[i] = 0u;
+}
+
+template <int RP>
+static void osjq_launch(EigPlan* p, hipStream_t st) {
+  const int nb = p->ldn / OSJ_CB, upr = nb / 2;
+  hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap);
+  hipLaunchKernelGGL(osjq_reset_kernel, dim3(1), dim3(1), 0, st, p->qctl);
+  hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->batch, upr,
+                     p->rep);
+  long units = (long)p->batch * upr;
+  const int grid = (int)(units < 512 ? units : 512);  // 2 resident workgroups per CU; fewer than that is fine too
+  hipLaunchKernelGGL((osjq_kernel<RP>), dim3(grid), dim3(256), 0, st, p->Gc, p->ldn, nb, p->batch, p->sweeps, p->sort_from,
+                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone);
 }
 
 // orders <= 256: round 0 carries the pairs inside the blocks, nb - 1 launches per sweep
@@ -935,6 +1114,16 @@ static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
 }
 
 static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
+  if (p->use_queue) {
+    switch (p->ldn) {
+      case 64: osjq_launch<1>(p, st); break;
+      case 128: osjq_launch<2>(p, st); break;
+      case 192: osjq_launch<3>(p, st); break;
+      default: osjq_launch<4>(p, st); break;
+    }
+    MUSED_LAUNCH_CHECK();
+    return MUSED_OK;
+  }
   for (int sw = 0; sw < p->sweeps; ++sw) {
     if (p->wavek) {
       switch (p->ldn) {
@@ -1014,6 +1203,26 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
       p->sort_from = 1 << 30;
       p->sortcols = 0;
     }
+    {
+      // persistent work-queue solver: wave-private kernel orders (<= 256), at most 255 global rounds per solve
+      // Default (MUSED_EIG_QUEUE unset): batches of at most 224 units per round (one sketch lane: 28 matrices x 4) --
+      // the persistent workgroups then occupy at most one slot on fewer than all CUs, so kernels of other streams
+      // (the adjacency / eigenstep chain, whose one-workgroup panel kernels need a whole CU) still find room.  Larger
+      // batches keep the launch-per-round graph: a persistent grid that fills the GPU for milliseconds would starve them.
+      // MUSED_EIG_QUEUE=1 / 0 forces it on / off.
+      const char* qe = getenv("MUSED_EIG_QUEUE");
+      const int nbq = p->ldn / OSJ_CB;
+      const bool fits = p->wavek && p->ldn <= 256 && nbq >= 2 && sweeps * (nbq - 1) <= 255 && batch <= (1 << 21);
+      const bool want = qe ? (qe[0] == '1') : ((long)batch * (nbq / 2) <= 224);
+      p->use_queue = (fits && want) ? 1 : 0;
+      if (p->use_queue) {
+        p->qcap = (unsigned)((long)batch * (nbq / 2) * (nbq - 1) * sweeps);
+        MUSED_CHECK_HIP(hipMalloc(&p->q, sizeof(unsigned) * (size_t)p->qcap));
+        MUSED_CHECK_HIP(hipMalloc(&p->qctl, sizeof(OsjqCtl)));
+        MUSED_CHECK_HIP(hipMalloc(&p->qdone, sizeof(int) * (size_t)batch));
+        MUSED_CHECK_HIP(hipMemset(p->qctl, 0, sizeof(OsjqCtl)));
+      }
+    }
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
     // stops after the first sweep that met no column pair with cos^2 above the threshold (osj_pair_active).  How many sweeps
     // that takes depends on the matrix (full-rank sketch buffers ~10 at order 256, rank-deficient ones up to 16).
@@ -1067,6 +1276,9 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->Gc) (void)hipFree(p->Gc);
   if (p->lam) (void)hipFree(p->lam);
   if (p->trace) (void)hipFree(p->trace);
+  if (p->q) (void)hipFree(p->q);
+  if (p->qctl) (void)hipFree(p->qctl);
+  if (p->qdone) (void)hipFree(p->qdone);
   if (p->ev0) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
@@ -1238,6 +1450,40 @@ int mused_debug_osj_time(const double* init, int batch, int variant, int reps, d
   (void)hipEventDestroy(e1);
   (void)hipFree(G);
   return MUSED_OK;
+}
+
+// Diagnostic (not part of the declared ABI): average time (ms, HIP events) of `reps` solves of `batch` matrices of order n
+// with one plan (created under the current environment: MUSED_EIG_QUEUE etc.); evals / V of the last solve are returned.
+int mused_debug_eig_time(const double* G, int n, int batch, int sweeps, int reps, double* evals, double* V, double* out_ms,
+                         int* out_err, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EigPlan* p = nullptr;
+  int rc = eig_plan_create(n, batch, sweeps, true, &p);
+  if (rc) return rc;
+  hipEvent_t e0, e1;
+  MUSED_CHECK_HIP(hipEventCreate(&e0));
+  MUSED_CHECK_HIP(hipEventCreate(&e1));
+  rc = eig_plan_run(p, G, evals, V, st);  // warm-up (graph upload)
+  MUSED_CHECK_HIP(hipStreamSynchronize(st));
+  MUSED_CHECK_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps && !rc; ++i) rc = eig_plan_run(p, G, evals, V, st);
+  MUSED_CHECK_HIP(hipEventRecord(e1, st));
+  MUSED_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MUSED_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *out_ms = ms / (reps > 0 ? reps : 1);
+  if (out_err) {
+    *out_err = 0;
+    if (p->use_queue) {
+      OsjqCtl c;
+      MUSED_CHECK_HIP(hipMemcpy(&c, p->qctl, sizeof(c), hipMemcpyDeviceToHost));
+      *out_err = c.error ? -1 : (int)c.tail;  // units queued in the last solve (or -1 on a timeout)
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  eig_plan_destroy(p);
+  return rc;
 }
 
 // Unit-testable primitive: eigen-decomposition of `batch` symmetric n x n fp64 matrices
