@@ -125,6 +125,16 @@ int mused_gemm_f64_batched(int a_kc, int b_kc, const double* A, long lda, long s
                            long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch,
                            double alpha, void* stream);
 
+/* ---- a10 / f2: the Lloyd iterations of perform_clustering (matrix_operations.py:149-153, sklearn KMeans) ------------
+ * The k-means++ seeding stays on the host (scikit-learn's own routine on the same RandomState stream); E / M steps and
+ * the stopping rule of sklearn's _kmeans_single_lloyd run here in fp64 with fixed-order sums.  X: n x d fp64 embedding
+ * (pitch ld), mean: its d column means, centers: k x d seeds of the CENTRED rows (in/out), tol = mean(var(X, 0)) * 1e-4.
+ * labels_out: n int32 (device); info_out (HOST, 4 ints) = {iterations, 1 strict / 2 tol / 0 max_iter, empty-cluster flag
+ * (result invalid: use scikit-learn for that window), 0}.  BLOCKING.  k * d <= 8192. */
+long mused_kmeans_ws_bytes(int n, int d, int k);
+int mused_kmeans_lloyd(const double* X, long ld, int n, int d, int k, const double* mean, double* centers, double tol,
+                       int max_iter, int* labels_out, int* info_out, void* ws, long ws_bytes, void* stream);
+
 /* ---- a5-a7: SeqBasedSWFD (swfd submodule; call sites main.py:62,65-67,70) ---------------------- */
 
 /* SeqBasedSWFD(N=, R=, d=, sketch_dim=) */

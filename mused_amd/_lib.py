@@ -53,6 +53,8 @@ _PROTOS = {
     "mused_syevj_batched": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mused_gemm_f64": (_i, [_i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _d, _vp]),
     "mused_gemm_f64_batched": (_i, [_i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _d, _vp]),
+    "mused_kmeans_ws_bytes": (_l, [_i, _i, _i]),
+    "mused_kmeans_lloyd": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _d, _i, _vp, C.POINTER(_i), _vp, _l, _vp]),
     "mused_swfd_create": (_i, [_l, _d, _i, _i, _i, C.POINTER(_vp)]),
     "mused_swfd_create_lanes": (_i, [_l, _d, _i, _i, _i, _i, C.POINTER(_vp)]),
     "mused_swfd_lanes": (_i, [_vp]),

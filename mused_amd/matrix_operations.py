@@ -171,6 +171,56 @@ def perform_clustering(matrix, n_clusters, seed):
     return KMeans(n_clusters=n_clusters, random_state=seed).fit_predict(matrix)
 
 
+_KM_WS = {}
+
+
+def perform_clustering_on_device(emb_dev, n_clusters, seed, emb_host=None, stream=None):
+    """The same labels as `perform_clustering` (matrix_operations.py:149-153) with the Lloyd iterations on the device
+    (SURVEY 8 f2).  The k-means++ seeding is scikit-learn's own routine on the host, fed the same
+    `RandomState(seed)` stream and the centred embedding exactly as `KMeans.fit` does (sklearn:cluster/_kmeans.py
+    `fit`: tolerance from the raw rows, X -= X.mean(0), row norms, `_init_centroids` -> `_kmeans_plusplus`); assignment,
+    centre update and the stopping rule of `_kmeans_single_lloyd` run in libmused_hip (csrc/kmeans.hip).
+    emb_dev: (n, d) fp64 CUDA tensor; emb_host: its host copy if the caller already has one.  Returns int32 labels
+    (NumPy).  Falls back to scikit-learn when a cluster runs empty (sklearn relocates it) or k * d > 8192."""
+    import ctypes as C
+
+    import torch
+    from sklearn.cluster import kmeans_plusplus
+    from sklearn.utils.extmath import row_norms
+
+    from . import _lib
+
+    n, d = emb_dev.shape
+    X = np.ascontiguousarray(emb_host if emb_host is not None else emb_dev.cpu().numpy(), dtype=np.float64)
+    if n_clusters * d > 8192 or n_clusters > n:
+        return perform_clustering(X, n_clusters, seed)
+    tol = float(np.mean(np.var(X, axis=0)) * 1e-4)   # KMeans._check_params_vs_input -> _tolerance, before centring
+    mean = X.mean(axis=0)
+    Xc = X - mean
+    centers, _ = kmeans_plusplus(Xc, n_clusters, x_squared_norms=row_norms(Xc, squared=True),
+                                 random_state=np.random.RandomState(seed))
+    st = stream if stream is not None else torch.cuda.current_stream()
+    with torch.cuda.stream(st):
+        key = (emb_dev.device, n, d, n_clusters, st.cuda_stream)
+        ws = _KM_WS.get(key)
+        if ws is None:
+            ws = torch.empty(int(_lib.lib().mused_kmeans_ws_bytes(n, d, n_clusters)), dtype=torch.uint8, device=emb_dev.device)
+            if len(_KM_WS) > 16:
+                _KM_WS.clear()
+            _KM_WS[key] = ws
+        mean_d = torch.from_numpy(mean).to(emb_dev.device)
+        cen_d = torch.from_numpy(np.ascontiguousarray(centers)).to(emb_dev.device)
+        labels = torch.empty(n, dtype=torch.int32, device=emb_dev.device)
+        info = (C.c_int * 4)()
+        Xd = emb_dev if emb_dev.stride(1) == 1 else emb_dev.contiguous()
+        _lib.call("mused_kmeans_lloyd", _eng.ptr(Xd), Xd.stride(0), n, d, n_clusters, _eng.ptr(mean_d), _eng.ptr(cen_d),
+                  tol, 300, _eng.ptr(labels), info, _eng.ptr(ws), ws.numel(), C.c_void_p(st.cuda_stream))
+        out = labels.cpu().numpy()
+    if info[2]:
+        return perform_clustering(X, n_clusters, seed)
+    return out
+
+
 def _overlap_costs(prev_clusters, new_clusters, min_overlap):
     up, un = np.unique(prev_clusters), np.unique(new_clusters)
     cost = np.full((len(up), len(un)), np.inf)

@@ -17,6 +17,7 @@ waits on the event and runs the scikit-learn / SciPy consumers in window order.
 from __future__ import annotations
 
 import os
+import threading
 import time
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
@@ -75,6 +76,11 @@ class StreamPipeline:
             self._blas_limit = threadpool_limits(limits=1, user_api="blas") if nk > 1 and async_labels else None
         except Exception:  # threadpoolctl missing: keep the library default
             self._omp_limit = None
+        # k-means of the embedding: Lloyd iterations on the device (host k-means++ seeding) unless
+        # MUSED_KMEANS=host; every label worker drives its own high-priority stream
+        self._km_device = os.environ.get("MUSED_KMEANS", "device") != "host"
+        self._km_local = threading.local()
+        self.km_device_windows = 0
         self._pending = deque()
         # the feature-row sketch is independent of the adjacency / eigenstep of the same window: it
         # runs on its own HIP stream and the two meet again before the results are handed to the host
@@ -148,7 +154,7 @@ class StreamPipeline:
     def _cluster(self, job):
         """Independent per window: wait for the embedding, k-means (main.py:97)."""
         ev, red_pin, sig_pin, n_clusters, trigger, t_start = job[:6]
-        flag_pin = job[6]
+        flag_pin, reduced_dev = job[6], job[7]
         torch.cuda.set_device(self._device)
         ev.synchronize()
         reduced_host, sigma_host = red_pin.numpy().copy(), sig_pin.numpy().copy()
@@ -158,7 +164,15 @@ class StreamPipeline:
             self._flag_pins.append(flag_pin)
             WindowEngine.check_rsvd_flags(flags_host)  # raised on the label worker, surfaces in flush()
         t0 = time.perf_counter()
-        clusters = mo.perform_clustering(reduced_host, n_clusters, self.seed)
+        if self._km_device and reduced_dev is not None and reduced_dev.dtype == torch.float64:
+            st = getattr(self._km_local, "stream", None)
+            if st is None:
+                st = self._km_local.stream = torch.cuda.Stream(priority=-1)
+            reduced_dev.record_stream(st)  # produced on the pipeline's stream, complete (ev), consumed on the worker's
+            clusters = mo.perform_clustering_on_device(reduced_dev, n_clusters, self.seed, emb_host=reduced_host, stream=st)
+            self.km_device_windows += 1
+        else:
+            clusters = mo.perform_clustering(reduced_host, n_clusters, self.seed)
         self.host_ms["kmeans"].append(1e3 * (time.perf_counter() - t0))
         return clusters, sigma_host
 
@@ -203,7 +217,7 @@ class StreamPipeline:
                 flag_pin.copy_(flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin)
+        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced)
         if self._pool is None:
             self._chain(self._cluster(job), job)
         else:

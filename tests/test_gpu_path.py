@@ -97,6 +97,37 @@ def test_text_modality_matches_reference_golden(eng):
             mo.create_adjacency_matrix(np.zeros((4, 2)), t, 2)
 
 
+@pytest.mark.parametrize("name", WINDOW_CASES)
+def test_device_kmeans_labels_match_reference_golden(eng, name):
+    """f2: Lloyd iterations on the device with scikit-learn's own k-means++ seeding on the host == the reference's
+    KMeans labels, bit for bit, on every golden window (structure-less Gaussian streams included: 14-40 iterations)."""
+    from mused_amd import matrix_operations as mo
+
+    g = load_golden(name)
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    for w in range(n // W):
+        sl = slice(w * W, (w + 1) * W)
+        fused = eng.fuse([eng.knn_adjacency(torch.from_numpy(m[sl]).cuda(), k, "l2") for m in mods])
+        emb, _ = eng.svd_reduce(fused, ell, seed, nnz_cap=W * k * len(mods))
+        km = mo.perform_clustering_on_device(emb, len(np.unique(labels[sl])), seed)
+        assert km.dtype == np.int32 and np.array_equal(km, g[f"w{w}_kmeans_labels"])
+
+
+def test_device_kmeans_against_sklearn_on_hard_cases():
+    """Unbalanced / overlapping / single-cluster inputs, k up to 40, d up to 200: device Lloyd == sklearn KMeans."""
+    from sklearn.cluster import KMeans
+
+    from mused_amd import matrix_operations as mo
+
+    rng = np.random.default_rng(12)
+    cases = [(3000, 16, 1), (3000, 16, 2), (2500, 64, 9), (4000, 200, 40), (700, 3, 5), (513, 128, 8)]
+    for n, d, k in cases:
+        X = rng.standard_normal((n, d)) + 3.0 * rng.standard_normal((k, d))[rng.integers(0, k, n)] * (rng.random((n, 1)) < 0.7)
+        ref = KMeans(n_clusters=k, random_state=3).fit_predict(X)
+        got = mo.perform_clustering_on_device(torch.from_numpy(X).cuda(), k, 3)
+        assert np.array_equal(got, ref.astype(np.int32)), (n, d, k)
+
+
 def test_rsvd_intermediate_components(eng):
     """Vt (after svd_flip) and the embedding against the oracle on a two-modality window."""
     from mused_amd import synth
@@ -282,6 +313,8 @@ def test_full_size_window_matches_reference_golden(name):
     np.testing.assert_allclose(emb[rows], g["w0_emb_sample"], atol=1e-7 * np.abs(g["w0_emb_sample"]).max())
     km = mo.perform_clustering(emb, len(np.unique(labels)), seed)
     assert np.array_equal(km.astype(np.int32), g["w0_kmeans_labels"])  # bit-exact event indices
+    kd = mo.perform_clustering_on_device(torch.from_numpy(emb).cuda(), len(np.unique(labels)), seed)
+    assert np.array_equal(kd, g["w0_kmeans_labels"])                   # ... also with the Lloyd iterations on the device
     eng.close()
 
 
