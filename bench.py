@@ -415,8 +415,7 @@ def main():
         if sketches and not args.no_single_lane:
             from mused_amd.swfd import SeqBasedSWFD
 
-            one = SeqBasedSWFD(N=W, R=R, d=D, sketch_dim=ell, lanes=1)
-            one.profile(True)
+            one = SeqBasedSWFD(N=W, R=R, d=D, sketch_dim=ell, lanes=1)   # (its rotations use the persistent osjq_kernel)
             nwin = min(T, 4)
             lats = []
             for t in range(T - nwin, T):   # the first is a warm-up (graph upload) and the sketch's halo window
@@ -434,7 +433,6 @@ def main():
                 pipe.flush()
                 th.join()
                 lats.append(time.perf_counter() - ts)
-            other_reads.append(one.profile_read())
             one.close()
             p50 = float(np.median(lats[1:])) if len(lats) > 1 else float(lats[0])
             single = {"rows_per_s": W / p50, "p50_window_ms": 1e3 * p50, "windows_timed": max(1, len(lats) - 1),

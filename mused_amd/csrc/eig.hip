@@ -752,7 +752,7 @@ __device__ __forceinline__ void osj_st(double* p, double v) {
 
 // One block-pair round of one matrix by one workgroup (the body of osjw_kernel): returns (per wave) whether a pair that
 // still matters was met.  kidx = index of the block pair in the round-robin of `round`.
-template <int RP, int SC, bool PREFIX, bool COH>
+template <int RP, int SC, bool PREFIX, bool COH, bool ST_WT = COH>
 __device__ __forceinline__ int osjw_unit(double* __restrict__ M, int ldn, int nb, int round, int kidx, double small2,
                                          int sortcols, OsjwShared<RP, SC>& sh, int tid) {
   static_assert(!PREFIX || SC == 8, "the in-launch intra-block schedule exists for 8-column sets only");
@@ -839,7 +839,7 @@ __device__ __forceinline__ int osjw_unit(double* __restrict__ M, int ldn, int nb
       const int colg = (pos < CB) ? (bp * CB + pos) : (bq * CB + pos - CB);
       const double dd = sh.dsc[wave][c];
 #pragma unroll
-      for (int i = 0; i < RP; ++i) osj_st<COH>(&M[(long)colg * ldn + lane + 64 * i], x[c * RP + i] * dd);
+      for (int i = 0; i < RP; ++i) osj_st<ST_WT>(&M[(long)colg * ldn + lane + 64 * i], x[c * RP + i] * dd);
     }
   } else {
     const int ca = set_col(ida), cb = set_col(idb);
@@ -848,8 +848,8 @@ __device__ __forceinline__ int osjw_unit(double* __restrict__ M, int ldn, int nb
       const double da = sh.dsc[wave][j], db = sh.dsc[wave][SC + j];
 #pragma unroll
       for (int i = 0; i < RP; ++i) {
-        osj_st<COH>(&M[(long)(ca + j) * ldn + lane + 64 * i], x[j * RP + i] * da);
-        osj_st<COH>(&M[(long)(cb + j) * ldn + lane + 64 * i], x[(SC + j) * RP + i] * db);
+        osj_st<ST_WT>(&M[(long)(ca + j) * ldn + lane + 64 * i], x[j * RP + i] * da);
+        osj_st<ST_WT>(&M[(long)(cb + j) * ldn + lane + 64 * i], x[(SC + j) * RP + i] * db);
       }
     }
   }
@@ -872,7 +872,11 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
   }
   __shared__ OsjwShared<RP, SC> sh;
   double* M = Gc + (long)blockIdx.y * ldn * ldn;
+#ifdef MUSED_OSJ_WT_STORES
+  const int active = osjw_unit<RP, SC, PREFIX, false, true>(M, ldn, nb, round, blockIdx.x, small2, sortcols, sh, threadIdx.x);
+#else
   const int active = osjw_unit<RP, SC, PREFIX, false>(M, ldn, nb, round, blockIdx.x, small2, sortcols, sh, threadIdx.x);
+#endif
   if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
 }
 
