@@ -179,9 +179,8 @@ __global__ void zero_ints_kernel(int* __restrict__ p, long n) {
   if (i < n) p[i] = 0;
 }
 
-// Zero-fill BY KERNEL.  Sequences that are captured into a hipGraph must not use hipMemsetAsync:
-// memset nodes of a captured graph wrote to stale addresses on replay with the HIP runtime torch
-// 2.10+rocm7.0 ships (observed on MI355X: corrupted neighbouring allocations, then a GPU memory fault).
+// Zero-fill by kernel, used inside captured sequences.  (Round 1 suspected captured hipMemsetAsync nodes of a memory
+// fault; tools/repro_graph_memset.hip does not reproduce that on this stack -- the kernel stays because it is free.)
 int zero_ints(int* p, long n, hipStream_t st) {
   hipLaunchKernelGGL(zero_ints_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n);
   MUSED_LAUNCH_CHECK();
