@@ -261,6 +261,104 @@ __global__ __launch_bounds__(256) void lu_trail_kernel(double* __restrict__ Y, i
   }
 }
 
+// ---- one launch per column (MUSED_LU_MODE=2; measured in round 2, NOT the default) ---------------------------------
+// Measured at n = 10^4, r = 138: 7.3 us per column launch (latency of its four dependent phases, not bandwidth) ->
+// eigenstep 22.6 ms instead of 24.8 alone, but 313 workgroups x 1,380 launches per window compete with the sketch
+// kernels for workgroup slots: 149 k rows/s instead of 152 k in the benchmark.  Kept for the stand-alone case.
+// The blocked variant above funnels every panel through ONE workgroup: 640 KB per 4 columns through one CU (26 us
+// alone, ~47 us beside the sketch kernels, whose workgroups leave no CU free for a 1024-thread workgroup).  Here a
+// column costs ONE launch of n / 32 small workgroups and nothing is ever single-workgroup:
+//   * every workgroup reduces the per-workgroup pivot candidates of column j itself (n / 32 (value, row) pairs = a few
+//     KB from L2; same tie rule: largest |a|, then smallest row) -- the redundant reduce replaces the pivot launch;
+//   * it loads the pivot row (r - j doubles) into LDS, eliminates its own 32 rows -- same expressions, element by element,
+//     as lu_update_kernel: results are bit-identical to the other two variants --, and writes its candidate for column
+//     j + 1 into the OTHER candidate buffer (workgroups of this launch may still be reading column j's).
+constexpr int LUC_ROWS = 32;  // rows per workgroup, 8 threads per row
+
+__device__ __forceinline__ void luc_candidates(const double* __restrict__ Y, int n, long ld, int jc,
+                                               const int* __restrict__ pivstep, int skip_row, double* __restrict__ pval,
+                                               int* __restrict__ pidx) {
+  // workgroup's best unpivoted |a| of column jc (ties: smaller row); LDS scratch is declared by the caller's scope
+  __shared__ double sv[LUC_ROWS];
+  __shared__ int si[LUC_ROWS];
+  const int lr = threadIdx.x >> 3, tx = threadIdx.x & 7;
+  const int row = blockIdx.x * LUC_ROWS + lr;
+  if (tx == 0) {
+    double a = -1.0;
+    if (row < n && row != skip_row && pivstep[row] == 0) a = fabs(Y[(long)row * ld + jc]);
+    sv[lr] = a;
+    si[lr] = row;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = sv[0];
+    int ix = si[0];
+    for (int w = 1; w < LUC_ROWS; ++w)
+      if (sv[w] > b) { b = sv[w]; ix = si[w]; }  // rows ascend with w: first maximum = smallest row
+    pval[blockIdx.x] = b;
+    pidx[blockIdx.x] = ix;
+  }
+}
+
+__global__ __launch_bounds__(256) void luc_first_kernel(const double* __restrict__ Y, int n, long ld,
+                                                       const int* __restrict__ pivstep, double* __restrict__ pval,
+                                                       int* __restrict__ pidx) {
+  luc_candidates(Y, n, ld, 0, pivstep, -1, pval, pidx);
+}
+
+__global__ __launch_bounds__(256) void luc_step_kernel(double* __restrict__ Y, int n, int r, long ld, int j, int k,
+                                                      int npart, int* __restrict__ pivstep, double* __restrict__ pval,
+                                                      int* __restrict__ pidx) {
+  extern __shared__ double s_prow[];  // [r - j]
+  __shared__ double s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ int s_win;
+  const double* cv = pval + (long)(j & 1) * npart;
+  const int* ci = pidx + (long)(j & 1) * npart;
+  double best = -2.0;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < npart; i += 256) {
+    const double a = cv[i];
+    const int ix = ci[i];
+    if (a > best || (a == best && ix < bi)) { best = a; bi = ix; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = s_val[0];
+    int ix = s_idx[0];
+    for (int w = 1; w < 4; ++w)
+      if (s_val[w] > b || (s_val[w] == b && s_idx[w] < ix)) { b = s_val[w]; ix = s_idx[w]; }
+    s_win = ix;
+  }
+  __syncthreads();
+  const int win = s_win;
+  for (int c = j + threadIdx.x; c < r; c += 256) s_prow[c - j] = Y[(long)win * ld + c];  // the pivot row is never updated
+  const int row = blockIdx.x * LUC_ROWS + (threadIdx.x >> 3);
+  const int tx = threadIdx.x & 7;
+  const bool mine = row < n && row != win && pivstep[row] == 0;  // read before the owner marks `win` (a different row anyway)
+  __syncthreads();
+  if (win / LUC_ROWS == (int)blockIdx.x && threadIdx.x == 0) pivstep[win] = j + 1;
+  if (mine) {
+    double* y = Y + (long)row * ld;
+    const double piv = s_prow[0];
+    const double a = y[j];
+    const double l = (piv != 0.0) ? a * (1.0 / piv) : a;
+    for (int c = j + 1 + tx; c < r; c += 8) y[c] -= l * s_prow[c - j];
+    if (tx == 0) y[j] = l;
+  }
+  if (j + 1 < k) {
+    __syncthreads();  // column j + 1 of this workgroup's rows is final (written by lanes of this workgroup)
+    luc_candidates(Y, n, ld, j + 1, pivstep, win, pval + (long)((j + 1) & 1) * npart, pidx + (long)((j + 1) & 1) * npart);
+  }
+}
+
 // ws_f64_len: doubles available behind prow (the blocked path needs LU_NB * (r + n))
 int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, long ws_f64_len, hipStream_t st) {
   // workspace layout, column-at-a-time path: pivstep[n] ints, then npart ints of candidate rows; prow[r] doubles,
@@ -269,9 +367,24 @@ int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, l
   const int npart = cdiv(n, LU_ROWS_PER_WG);
   int zrc = zero_ints(pivstep, n, st);
   if (zrc) return zrc;
-  const char* ub = getenv("MUSED_LU_BLOCKED");
-  const bool blocked = n <= 10240 && ws_f64_len >= (long)LU_NB * ((long)r + n) && !(ub && ub[0] == '0');
-  if (blocked) {
+  static const int lu_mode = [] {  // 0 column-at-a-time (2 launches per column), 1 blocked panels, 2 one launch per column
+    const char* ub = getenv("MUSED_LU_BLOCKED");
+    const char* um = getenv("MUSED_LU_MODE");
+    if (um) return atoi(um);
+    return (ub && ub[0] == '0') ? 0 : 1;
+  }();
+  const int npc = cdiv(n, LUC_ROWS);
+  // candidate buffers of the one-launch-per-column path: 2 x npc doubles and 2 x npc ints behind prow[r]
+  const bool percol = lu_mode == 2 && ws_f64_len >= (long)r + 3l * npc + 2;
+  const bool blocked = !percol && lu_mode != 0 && n <= 10240 && ws_f64_len >= (long)LU_NB * ((long)r + n);
+  if (percol) {
+    double* pval = prow + r;
+    int* pidx = reinterpret_cast<int*>(pval + 2l * npc);
+    hipLaunchKernelGGL(luc_first_kernel, dim3(npc), dim3(256), 0, st, Y, n, ld, pivstep, pval, pidx);
+    for (int j = 0; j < k; ++j)
+      hipLaunchKernelGGL(luc_step_kernel, dim3(npc), dim3(256), sizeof(double) * (r - j), st, Y, n, r, ld, j, k, npc, pivstep,
+                         pval, pidx);
+  } else if (blocked) {
     double* prowN = prow;
     double* pc = prow + (long)LU_NB * r;
     int nbp = 0;
