@@ -191,10 +191,23 @@ extern "C" {
 // Workspace handle for problems up to n_max rows, r_max = n_components + n_oversamples random
 // columns, nnz_cap edges in the fused adjacency.  `sweeps` = Jacobi sweeps of the r x r solve
 // (0 -> default 12).
+static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int sweeps);
+int mused_rsvd_destroy(void* handle);
+
 int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out) {
   MUSED_REQUIRE(out && n_max >= 2 && r_max >= 1 && r_max <= 1022 && nnz_cap >= 1, "mused_rsvd_create: bad arguments");
   Rsvd* h = new Rsvd();
   memset(h, 0, sizeof(*h));
+  const int rc = rsvd_create_impl(h, n_max, r_max, nnz_cap, sweeps);
+  if (rc) {  // release what was allocated before the failure
+    (void)mused_rsvd_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MUSED_OK;
+}
+
+static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int sweeps) {
   h->n_max = n_max; h->r_max = r_max; h->nnz_cap = nnz_cap;
   h->sweeps = sweeps > 0 ? sweeps : 16;  // cap of the adaptive sweep count
   h->eig_n = (r_max + 1) & ~1;
@@ -222,7 +235,6 @@ int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out
   if ((rc = gemm_f64_prepare_all())) return rc;
   const char* ng = getenv("MUSED_NO_GRAPH");
   h->use_graph = !(ng && ng[0] == '1');
-  *out = h;
   return MUSED_OK;
 }
 

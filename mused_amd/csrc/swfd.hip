@@ -582,6 +582,7 @@ extern "C" {
 // Replaces SeqBasedSWFD.__init__ (call site main.py:62: N=window_size, R=max row norm^2,
 // d=row length, sketch_dim=l).  sweeps: Jacobi sweeps per rotation (0 -> default).
 int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int lanes, void** out);
+int mused_swfd_destroy(void* handle);
 
 int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) {
   return mused_swfd_create_lanes(N, R, d, ell, sweeps, 1, out);
@@ -589,12 +590,24 @@ int mused_swfd_create(long N, double R, int d, int ell, int sweeps, void** out) 
 
 // `lanes` independent sketch sets (e.g. the windows of `lanes` contiguous blocks of the stream) advanced
 // in lockstep by the same launches: every append feeds the same number of rows to every lane.
+static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweeps, int lanes);
+
 int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int lanes, void** out) {
   MUSED_REQUIRE(out && N >= 1 && d >= 1 && ell >= 1 && ell <= 256, "mused_swfd_create: need N, d >= 1 and 1 <= sketch_dim <= 256");
   MUSED_REQUIRE(lanes >= 1 && lanes <= 64, "mused_swfd_create_lanes: 1 <= lanes <= 64");
   MUSED_REQUIRE(N < (1l << 31), "mused_swfd_create: N too large");
   Swfd* h = new Swfd();
   memset(h, 0, sizeof(*h));
+  const int rc = swfd_create_impl(h, N, R, d, ell, sweeps, lanes);
+  if (rc) {  // a later allocation failed: release what the earlier ones took (the error message is kept)
+    (void)mused_swfd_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MUSED_OK;
+}
+
+static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweeps, int lanes) {
   h->N = (int)N; h->R = R; h->d = d; h->ell = ell;
   double r1 = R > 1.0 ? R : 1.0;
   int lg = 0;
@@ -662,7 +675,6 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
         return rc;
     }
   }
-  *out = h;
   return MUSED_OK;
 }
 

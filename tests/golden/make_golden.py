@@ -149,7 +149,7 @@ def case_windows(tag, kind, n, d, W, ell, k, seed, two_mod=False, **kw):
     save(tag, **out)
 
 
-def case_stream(tag, kind, n, d, W, ell, k, seed, approach="sSVDMC", two_mod=False, **kw):
+def case_stream(tag, kind, n, d, W, ell, k, seed, approach="sSVDMC", two_mod=False, ratio=1, **kw):
     """Whole-run event labels through the reference's own window loop (main.py:13-130)."""
     if two_mod:
         mods, labels = synth.two_modality_blob_stream(n, d, seed, **kw)
@@ -171,7 +171,7 @@ def case_stream(tag, kind, n, d, W, ell, k, seed, approach="sSVDMC", two_mod=Fal
     try:
         quiet(
             ref_main.process_streaming_data, {}, mods64, types_, W, ell, k, len(np.unique(labels)), seed,
-            approach, labels, 1, 0.0, "types", False, 1.5, 2,
+            approach, labels, ratio, 0.0, "types", False, 1.5, 2,
         )
     finally:
         ref_me.compute_all_metrics = orig
@@ -271,6 +271,9 @@ def main():
     if only:
         if "cosine" in only:
             case_cosine()
+        if "c1_stream_hop2_blob_s0" in only:   # hopping windows (step_window_ratio = 2, main.py:32)
+            case_stream("c1_stream_hop2_blob_s0", "blob", 3000, 64, 500, 16, 50, 0, ratio=2, n_centres=4, sep=2.0)
+            case_stream("c1_stream_hop4_gauss_s1", "gauss", 2000, 64, 400, 16, 30, 1, ratio=4)
         if "bench_c2_blob_s0" in only:   # bench.py default stream: 20 windows of BASELINE config 2
             case_bench_stream("bench_c2_blob_s0", "blob", 20, 10000, 1024, 128, 50, 0)
         if "c3_blob_s0" in only:   # BASELINE config 3 at its real shape
@@ -289,6 +292,8 @@ def main():
     for seed in (0, 1):
         case_stream(f"c1_stream_blob_s{seed}", "blob", 5000, 64, 500, 16, 50, seed, n_centres=4, sep=2.0)
     case_stream("c1_stream_gauss_s0", "gauss", 5000, 64, 500, 16, 50, 0)
+    case_stream("c1_stream_hop2_blob_s0", "blob", 3000, 64, 500, 16, 50, 0, ratio=2, n_centres=4, sep=2.0)
+    case_stream("c1_stream_hop4_gauss_s1", "gauss", 2000, 64, 400, 16, 30, 1, ratio=4)
     case_stream("c4s_stream_twomod_s0", "blob2", 2048, 32, 512, 16, 20, 0, two_mod=True, n_centres=4)
     # a mid-size window in the C2 aspect ratio that the CPU suite can afford
     case_windows("c2m_blob_s0", "blob", 2000, 256, 2000, 64, 50, 0, n_centres=8, sep=2.0)

@@ -36,6 +36,19 @@ def test_stream_event_labels_bit_exact(name, async_labels):
     assert hashlib.sha256(out.astype(np.int64).tobytes()).hexdigest() == str(g["labels_sha"])
 
 
+@pytest.mark.parametrize("name,ratio", [("c1_stream_hop2_blob_s0", 2), ("c1_stream_hop4_gauss_s1", 4)])
+def test_hopping_windows_match_reference_golden(name, ratio):
+    """step_window_ratio = 2 and 4 (main.py:32) against fixtures produced by the reference's own window loop."""
+    from mused_amd.pipeline import StreamPipeline
+
+    g = load_golden(name)
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    pipe = StreamPipeline(W, ell, k, seed, "sSVDMC", step_window_ratio=ratio)
+    out = pipe.run(mods, labels)
+    pipe.close()
+    assert np.array_equal(out.astype(np.int64), g["all_clusters"])
+
+
 def test_process_streaming_data_signature_and_hopping_windows():
     """Same positional parameters as main.py:13; step_window_ratio = 2 (hopping windows, main.py:32)
     against the oracle's window loop."""

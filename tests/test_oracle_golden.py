@@ -60,6 +60,17 @@ def test_stream_event_labels_bit_exact(name):
     assert hashlib.sha256(out.astype(np.int64).tobytes()).hexdigest() == str(g["labels_sha"])
 
 
+@pytest.mark.parametrize("name,ratio", [("c1_stream_hop2_blob_s0", 2), ("c1_stream_hop4_gauss_s1", 4)])
+def test_hopping_windows_match_reference(name, ratio):
+    """step_window_ratio > 1 (main.py:32): overlapping windows, positional label matching -- `all_clusters` of the
+    reference's own window loop reproduced bit for bit."""
+    g = load_golden(name)
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    out = mo.process_streaming_data([m.astype(np.float64) for m in mods], [""], W, ell, k, seed, "sSVDMC", labels,
+                                    step_window_ratio=ratio)
+    assert np.array_equal(out.astype(np.int64), g["all_clusters"])
+
+
 def test_text_branch_matches_reference():
     """a2: the reference's own `text` branch (matrix_operations.py:91-110) on synthetic string records."""
     g = load_golden("cosine")
