@@ -29,6 +29,7 @@ struct Swfd {
   long i;    // rows seen so far
   int pend;  // rows appended since the last rotation (they sit raw in every buffer)
   long restart_mark;  // value of i for which the epoch-start swap has already been done
+  int skip_dead;  // 1: MAIN sketches that can no longer be selected in their epoch are frozen (swfd_rep_kernel)
   bool twin;  // MAIN and AUX of every level still identical (both empty at the start of this epoch, no state imported)
   int sweeps;
   // persistent state
@@ -116,7 +117,17 @@ __global__ void swfd_set_now_kernel(long long* now, long long v) { *now = v; }
 // rotate product; the others read the representative's and apply their own threshold (results unchanged: identical
 // inputs through the same deterministic kernels).  On the 8-blob stream of the benchmark 3 of 28 sketches are
 // duplicates in steady state, 17 of 28 in the first window of a stream.  One thread per (lane, kind).
-__global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains, int* __restrict__ rep, int twin) {
+//
+// DEAD MAIN sketches (round 2).  get() only ever reads the MAIN sketch of a level whose ring has lost no snapshot that
+// is still inside the window (dropped + N <= now; the top level is the fallback), and at the first row of the next epoch
+// MAIN is overwritten by AUX.  So once a MAIN sketch below the top level has lost a snapshot created in the CURRENT epoch
+// (dropped > epoch start) it cannot be selected again before it is overwritten: nothing it computes from then on is
+// observable.  Such sketches get rep = -1 and are skipped by the Gram / Jacobi / decide / rotate / scatter launches until
+// the epoch ends -- 55 % of the MAIN rotations on the benchmark stream (levels 0-3 after three rotations, levels 4-9
+// after ~32 of 78).  Exact: every get() returns what it would have returned; only `export_half(0)` of a dead level
+// shows the frozen state.  (Never in the first epoch of a stream, where the AUX chain borrows MAIN's solves.)
+__global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains, int* __restrict__ rep, int twin,
+                                const long long* __restrict__ dropped, long long epoch_start, int skip_dead) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nchains) return;
   // first epoch of a stream: AUX is the twin of MAIN (both started empty) -> the AUX chain maps onto the MAIN chain
@@ -136,6 +147,9 @@ __global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains
     if (meta[(base + j) * 4 + 3] != 0) r = base + j;
     rep[base + j] = r;
   }
+  if (skip_dead && !twin && (c & 1) == 0)  // MAIN chain (sketch index = lane * 2L + kind * L + level, kind 0)
+    for (int j = 0; j < L - 1; ++j)
+      if (dropped[base + j] > epoch_start) rep[base + j] = -1;
 }
 
 // One workgroup per sketch: expiry, eigenvalue ordering, shrink, dump/keep plan, Wc.
@@ -155,6 +169,7 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
   const int s = blockIdx.x, t = threadIdx.x;
   const long long now = *now_p;
   const int sr = rep ? rep[s] : s;  // whose eigen-decomposition this sketch uses (its own unless it is a duplicate)
+  if (sr < 0) return;               // dead MAIN sketch (swfd_rep_kernel): frozen until the epoch ends
   const double* ev = evals + (long)sr * ldu;
   const double* Us = U + (long)sr * ldu * ldu;
   if (t < n2) lam[t] = ev[t];
@@ -234,6 +249,7 @@ __global__ void swfd_scatter_kernel(const double* __restrict__ T, const int* __r
                                     double* __restrict__ buf, double* __restrict__ queue, int n2, int ell, int cap,
                                     int d, const int* __restrict__ rep) {
   const int rho = blockIdx.x, s = blockIdx.y;
+  if (rep && rep[s] < 0) return;  // dead MAIN sketch: frozen
   const double* Ts = T + (long)(rep ? rep[s] : s) * ell * d;
   if (rho < ell && plan[(s * ell + rho) * 2] == 2) {
     const int slot = plan[(s * ell + rho) * 2 + 1];
@@ -257,7 +273,7 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
   hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
   if (h->rep)
     hipLaunchKernelGGL(swfd_rep_kernel, dim3(cdiv(2 * h->lanes, 64)), dim3(64), 0, st, h->meta, h->L, 2 * h->lanes, h->rep,
-                       h->twin ? 1 : 0);
+                       h->twin ? 1 : 0, h->dropped, (long long)(((h->i - 1) / h->N) * h->N), h->skip_dead);
   if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
                      (long)n2 * n2, n2, n2, d, S, 1.0, st, h->rep)))
     return rc;
@@ -634,6 +650,8 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
   {
     const char* dd = getenv("MUSED_SWFD_DEDUPE");
     if (!(dd && dd[0] == '0')) ALLOC(h->rep, 4 * S);
+    const char* sd = getenv("MUSED_SWFD_SKIP_DEAD");
+    h->skip_dead = (sd && sd[0] == '0') ? 0 : 1;
   }
   ZALLOC(h->dropped, 8 * S);
   ALLOC(h->theta, 8 * S);
