@@ -108,3 +108,47 @@ def test_mused_wiring_transposed_sketch():
         sk.fit(fused[r, :].reshape(1, -1))
     red = sk.get()[0]
     assert red.shape[0] != W and red.T.shape == (W, ell)
+
+
+def test_frozen_main_sketches_are_never_observed():
+    """The device freezes a MAIN sketch (below the top level) once it has lost a snapshot created in the current epoch:
+    it cannot be selected again before the epoch-start swap overwrites it (swfd.hip, swfd_rep_kernel).  Restated on the
+    specification: skipping those rotations changes no get() -- queried after EVERY row block, over several epochs, on
+    streams that make low levels drop continuously and high levels rarely."""
+    from oracle import swfd_oracle as so
+
+    class Frozen(so.SeqBasedSWFD):
+        frozen_rotations = 0
+
+        def _rotate_all(self):
+            es = ((self.i - 1) // self.N) * self.N
+            first_epoch = self.i <= self.N
+            for j, sk in enumerate(self.main):
+                if not first_epoch and j < self.L - 1 and sk.dropped_t > es:
+                    Frozen.frozen_rotations += 1
+                    continue
+                sk.rotate(self.pending, self.i, self.N, self.ell)
+            for sk in self.aux:
+                sk.rotate(self.pending, self.i, self.N, self.ell)
+            self.pending = np.zeros((0, self.d))
+
+    total = 0
+    for kind, seed in (("blob", 1), ("gauss", 2), ("fd", 3)):
+        N, ell, d = 300, 6, 24
+        X, _ = synth.make_stream(kind, 5 * N + 41, d, seed)
+        X = X.astype(np.float64)
+        X[N // 2 : N // 2 + 40] *= 9.0  # a burst of heavy rows: dumps (and ring overflows) on the middle levels too
+        R = float((X**2).sum(1).max())
+        a, b = so.SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell), Frozen(N=N, R=R, d=d, sketch_dim=ell)
+        t = 0
+        rng = np.random.default_rng(seed)
+        while t < len(X):
+            step = int(rng.integers(1, 19))
+            a.fit(X[t : t + step])
+            b.fit(X[t : t + step])
+            t += step
+            Ba, sa, la, da = a.get()
+            Bb, sb, lb, db = b.get()
+            assert la == lb and da == db and np.array_equal(Ba, Bb) and np.array_equal(sa, sb), (kind, t)
+        total += Frozen.frozen_rotations
+    assert total > 500  # the rule did skip a substantial share of the MAIN rotations
