@@ -184,54 +184,92 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
     order[rank] = t;
   }
   __syncthreads();
+  // ---- expiry, shrink, keep / dump plan: all threads (round 2; the same decisions, in the same order, as the serial
+  // form: timestamps in the ring ascend from its head, the j-th dump of this rotation lands (head + count + j) mod cap
+  // whatever is evicted meanwhile, and at most count old entries are evicted because a rotation dumps <= l = cap / 2) ----
+  __shared__ int s_scan[1024];
+  __shared__ int s_tot[4];
+  const int head0 = meta[s * 4 + 1], cnt0 = meta[s * 4 + 2];
+  long long* q = qt + (long)s * cap;
+  // (a) expired snapshots: a prefix of the ring
+  int expired = 0;
+  for (int k = t; k < cnt0; k += 1024) expired += (q[(head0 + k) % cap] + N <= now) ? 1 : 0;
+  s_scan[t] = expired;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) s_scan[t] += s_scan[t + o];
+    __syncthreads();
+  }
+  const int nexp = s_scan[0];
+  __syncthreads();
+  const int head1 = (head0 + nexp) % cap, cnt1 = cnt0 - nexp;
+  // (b) per direction: shrunk energy, keep / dump
+  const double l0 = lam[order[0]];
+  const double delta = lam[order[ell - 1]] > 0.0 ? lam[order[ell - 1]] : 0.0;
+  const double tol = 1e-10 * (l0 > 0.0 ? l0 : 0.0);
+  const double th = theta[s];
+  int kind = 0, near = 0;
+  double sc = 0.0;
+  if (t < ell) {
+    const double l = lam[order[t]];
+    double s2 = l - delta;
+    s2 = s2 > 0.0 ? s2 : 0.0;
+    if (s2 > tol) {
+      sc = sqrt(s2 / l);
+      if (cols) sc /= l;  // the raw column is lam u
+      kind = (s2 >= th) ? 2 : 1;
+      near = (kind == 2 && s2 < 2.0 * th) ? 1 : 0;  // dumped here but kept one level up: this sketch parts with the next level
+    }
+    scale[t] = sc;
+  }
+  // (c) positions: exclusive prefix counts of keeps and of dumps over the directions in order
+  auto block_count = [&](int flag, int& total) -> int {  // exclusive prefix of `flag` over threads 0 .. 1023
+    s_scan[t] = flag;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int v = (t >= o) ? s_scan[t - o] : 0;
+      __syncthreads();
+      s_scan[t] += v;
+      __syncthreads();
+    }
+    total = s_scan[1023];
+    const int ex = s_scan[t] - flag;
+    __syncthreads();
+    return ex;
+  };
+  int nk = 0, nd = 0, nnear = 0;
+  const int kpos = block_count(kind == 1 ? 1 : 0, nk);
+  const int dpos = block_count(kind == 2 ? 1 : 0, nd);
+  (void)block_count(near, nnear);
+  const int nevict = (cnt1 + nd > cap) ? (cnt1 + nd - cap) : 0;  // <= cnt1
+  // the newest evicted timestamp (read before the new stamps overwrite the ring)
   if (t == 0) {
-    int nk = 0, head = meta[s * 4 + 1], cnt = meta[s * 4 + 2], ndump = 0;
     long long drop = dropped[s];
-    long long* q = qt + (long)s * cap;
-    while (cnt > 0 && q[head] + N <= now) {  // expiry
-      head = (head + 1) % cap;
-      --cnt;
+    if (nevict > 0) {
+      const long long ts = q[(head1 + nevict - 1) % cap];
+      drop = ts > drop ? ts : drop;
     }
-    const double l0 = lam[order[0]];
-    const double delta = lam[order[ell - 1]] > 0.0 ? lam[order[ell - 1]] : 0.0;
-    const double tol = 1e-10 * (l0 > 0.0 ? l0 : 0.0);
-    const double th = theta[s];
-    for (int i = 0; i < ell; ++i) {
-      const double l = lam[order[i]];
-      double s2 = l - delta;
-      s2 = s2 > 0.0 ? s2 : 0.0;
-      int kind = 0, pos = 0;
-      double sc = 0.0;
-      if (s2 > tol) {
-        sc = sqrt(s2 / l);
-        if (cols) sc /= l;  // the raw column is lam u
-        if (s2 >= th) {  // dump
-          if (cnt == cap) {
-            drop = q[head] > drop ? q[head] : drop;
-            head = (head + 1) % cap;
-            --cnt;
-          }
-          pos = (head + cnt) % cap;
-          q[pos] = now;
-          ++cnt;
-          ndump += (s2 < 2.0 * th);  // dumped here but kept one level up: this sketch parts with the next level
-          kind = 2;
-        } else {
-          pos = nk;
-          keep_src[s * ell + nk] = i;
-          ++nk;
-          kind = 1;
-        }
-      }
-      plan[(s * ell + i) * 2 + 0] = kind;
-      plan[(s * ell + i) * 2 + 1] = pos;
-      scale[i] = sc;
-    }
-    meta[s * 4 + 0] = nk;
-    meta[s * 4 + 1] = head;
-    meta[s * 4 + 2] = cnt;
-    meta[s * 4 + 3] += ndump;
     dropped[s] = drop;
+    s_tot[0] = 0;
+  }
+  __syncthreads();
+  if (t < ell) {
+    int pos = 0;
+    if (kind == 1) {
+      pos = kpos;
+      keep_src[s * ell + kpos] = t;
+    } else if (kind == 2) {
+      pos = (head1 + cnt1 + dpos) % cap;
+      q[pos] = now;
+    }
+    plan[(s * ell + t) * 2 + 0] = kind;
+    plan[(s * ell + t) * 2 + 1] = pos;
+  }
+  if (t == 0) {
+    meta[s * 4 + 0] = nk;
+    meta[s * 4 + 1] = (head1 + nevict) % cap;
+    meta[s * 4 + 2] = cnt1 + nd - nevict;
+    meta[s * 4 + 3] += nnear;
   }
   __syncthreads();
   if (sr != s) return;  // the rotate product is taken from the representative
