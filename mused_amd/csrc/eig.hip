@@ -21,7 +21,9 @@ struct EigPlan {
   int ldn;     // OSJ: padded order (multiple of 64) = threads per workgroup
   double* Gc;  // OSJ: batch x ldn x ldn, column-major working copy
   double* lam; // OSJ: batch x ldn column norms
-  int* notconv;  // OSJ: sweeps x batch convergence flags
+  int* notconv;  // OSJ: (sweeps * rps) x batch flags: a pair that still matters was met in that launch round
+  int rps;       // launch rounds per sweep: nb - 1 (orders <= 256: round 0 carries the pairs inside the blocks) or nb
+  int* qclean;   // queue solver: consecutive clean rounds per matrix
   int wavek;     // OSJ: 1 = wave-private kernel (orders <= 256)
   bool direct;   // OSJ: the caller fills Gc itself (n == ldn): no pack pass
   const int* rep; // optional: matrix b is a duplicate of matrix rep[b] != b and is not solved
@@ -59,8 +61,8 @@ struct EigPlan {
 // products of each step reduced across the workgroup (in-wave transpose-reduce + one LDS hop).
 // Column norms are carried in LDS and updated from the rotation, so each step reduces CB values.
 constexpr int OSJ_CB = 32;
-// Adaptive sweeps: a sweep ends the solve if none of its rotations started from a column pair that still
-// matters.  With tr = trace(G) (>= lam_max), columns g_j = lam_j u_j, pq = g_p . g_q, a pair matters when
+// Adaptive sweeps: the solve of a matrix ends once a sweep's worth of consecutive launch rounds (every column pair
+// once; osj_finished) started no rotation from a column pair that still matters.  With tr = trace(G) (>= lam_max), columns g_j = lam_j u_j, pq = g_p . g_q, a pair matters when
 //   cos^2 = pq^2 / (pp qq) > cos2         (what a sweep of smaller cosines leaves behind is second order), and
 //   min(pp, qq) > (1e-12 tr)^2            (columns in the numerical null space never settle relatively).
 // cos2 = 1e-10 in the wave-private kernel: with its block-pair sort, eigenvectors come out orthogonal to 2e-10
@@ -71,6 +73,17 @@ constexpr int OSJ_CB = 32;
 constexpr double OSJ_CONV_COS2_WAVE = 1e-10, OSJ_CONV_COS2_ROW = 1e-14;
 __device__ __forceinline__ bool osj_pair_active(double pq2, double pp, double qq, double floor2, double cos2) {
   return (pq2 > cos2 * (pp * qq)) & (pp > floor2) & (qq > floor2);
+}
+
+// ROLLING STOP (round 2): flags are kept per LAUNCH ROUND (fr = sweep * rps + position in the sweep; rps = launches per
+// sweep), and a matrix stops as soon as the last rps rounds -- any rps consecutive rounds of the cyclic schedule meet
+// every column pair exactly once -- raised no flag, instead of waiting for a clean sweep that starts at a sweep boundary
+// (on average half a sweep less).
+__device__ __forceinline__ bool osj_finished(const int* __restrict__ notconv, int fr, int rps, int batch, int m) {
+  if (!notconv || fr < rps) return false;
+  int any = 0;
+  for (int i = 1; i <= rps; ++i) any |= notconv[(long)(fr - i) * batch + m];
+  return any == 0;
 }
 
 __host__ __device__ constexpr int osj_pair_p(int m2, int step, int k) {
@@ -291,7 +304,7 @@ __host__ __device__ constexpr int osj_sched_q(int c2, int step, int k) {
 
 template <int CB, int NT, int MODE, int DBG = 0>
 __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, int n, int ldn, int nb, int round,
-                                                      int* __restrict__ notconv, int sweep,
+                                                      int* __restrict__ notconv, int fr, int rps,
                                                       const double* __restrict__ trace, int sortcols,
                                                       const int* __restrict__ rep) {
   if (rep && rep[blockIdx.y] != (int)blockIdx.y) return;  // duplicate of another matrix of the batch
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
   // to lambda_j u_j: pairs inside the numerical null space never settle in the relative sense and carry
   // nothing the path uses); a matrix whose previous sweep set nothing is converged (that sweep left
   // every such cosine below ~1e-13 * n by quadratic convergence) and its workgroups return at once.
-  if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;
+  if (osj_finished(notconv, fr, rps, gridDim.y, blockIdx.y)) return;
   double small2 = 0.0;
   if (trace) {
     const double tr = trace[blockIdx.y];
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(NT) void osj_round_kernel(double* __restrict__ Gc, 
     const int col = (pos < CB) ? (bp * CB + pos) : (bq * CB + pos - CB);
     M[(long)col * ldn + r] = x[j] * dsc[wave][j];
   }
-  if (notconv && wave == 0 && __any(active) && lane == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
+  if (notconv && wave == 0 && __any(active) && lane == 0) atomicOr(&notconv[(long)fr * gridDim.y + blockIdx.y], 1);
   (void)n;
 }
 
@@ -742,12 +755,12 @@ __device__ __forceinline__ int osjw_unit(double* __restrict__ M, int ldn, int nb
 template <int RP, int SC, bool PREFIX>
 __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kernel(double* __restrict__ Gc, int ldn, int nb,
                                                                                   int round,
-                                                                                  int* __restrict__ notconv, int sweep,
+                                                                                  int* __restrict__ notconv, int fr, int rps,
                                                                                   const double* __restrict__ trace,
                                                                                   int sortcols,
                                                                                   const int* __restrict__ rep) {
   if (rep && rep[blockIdx.y] != (int)blockIdx.y) return;  // duplicate of another matrix of the batch
-  if (notconv && sweep > 0 && notconv[(sweep - 1) * gridDim.y + blockIdx.y] == 0) return;  // see osj_round_kernel
+  if (osj_finished(notconv, fr, rps, gridDim.y, blockIdx.y)) return;  // see osj_round_kernel
   double small2 = notconv ? 0.0 : -1.0;
   if (trace) {
     const double tr = trace[blockIdx.y];
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
 #else
   const int active = osjw_unit<RP, SC, PREFIX, false>(M, ldn, nb, round, blockIdx.x, small2, sortcols, sh, threadIdx.x);
 #endif
-  if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[sweep * gridDim.y + blockIdx.y], 1);
+  if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[(long)fr * gridDim.y + blockIdx.y], 1);
 }
 
 // ---- persistent work-queue solver (orders <= 256) ---------------------------------------------------------------
@@ -782,8 +795,8 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
 // Arithmetic and order of operations per matrix are those of the launch-per-round solver: results are bit-identical.
 constexpr unsigned OSJQ_EXIT = 0xffffffffu;
 
-__global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict__ q, int* __restrict__ qdone, int batch,
-                                 int upr, const int* __restrict__ rep) {
+__global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict__ q, int* __restrict__ qdone,
+                                 int* __restrict__ qclean, int batch, int upr, const int* __restrict__ rep) {
   // (q has been zeroed by the launch before)
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m == 0) {
@@ -791,6 +804,7 @@ __global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict
   }
   if (m >= batch) return;
   qdone[m] = 0;
+  qclean[m] = 0;
   if (rep && rep[m] != m) return;
   const unsigned pos = atomicAdd(&ctl->tail, (unsigned)upr);
   for (int i = 0; i < upr; ++i) q[pos + i] = 1u + (((unsigned)m * 256u + 0u) * 4u + (unsigned)i);
@@ -803,7 +817,8 @@ template <int RP>
 __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, int ldn, int nb, int batch, int max_sweeps,
                                                      int sort_from, int* __restrict__ notconv,
                                                      const double* __restrict__ trace, unsigned* __restrict__ q,
-                                                     unsigned qcap, OsjqCtl* __restrict__ ctl, int* __restrict__ qdone) {
+                                                     unsigned qcap, OsjqCtl* __restrict__ ctl, int* __restrict__ qdone,
+                                                     int* __restrict__ qclean) {
   __shared__ OsjwShared<RP, 8> sh;
   __shared__ unsigned s_item;
   const int rounds = nb - 1, upr = nb / 2;
@@ -850,7 +865,7 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
     asm volatile("" : "+v"(tid));
     if (r == 0) active = osjw_unit<RP, 8, true, true>(M, ldn, nb, 0, k, small2, so, sh, tid);
     else active = osjw_unit<RP, 8, false, true>(M, ldn, nb, r, k, small2, so, sh, tid);
-    if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[sweep * batch + m], 1);
+    if (notconv && __any(active) && (threadIdx.x & 63) == 0) atomicOr(&notconv[(long)R * batch + m], 1);
     // publish: every wave drains its write-through stores (and its flag atomic) ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // ... all of them have; LDS of this unit is free again
@@ -858,11 +873,14 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
       const int old = atomicAdd(&qdone[m], 1);
       if (old == upr - 1) {  // last unit of round R of matrix m: nobody else touches this matrix now
         __hip_atomic_store(&qdone[m], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool fin = false;
-        if (r == rounds - 1) {
-          fin = sweep + 1 >= max_sweeps;
-          if (notconv && !fin)
-            fin = __hip_atomic_load(&notconv[sweep * batch + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        // rolling stop, as osj_finished: the matrix ends with the first round that closes `rounds` clean rounds in a row
+        bool fin = (r == rounds - 1) && (sweep + 1 >= max_sweeps);
+        if (notconv && !fin) {
+          const int flag = __hip_atomic_load(&notconv[(long)R * batch + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (one lane per round touches qclean[m], but rounds of a matrix end on different CUs: agent-scope accesses)
+          const int clean = flag ? 0 : __hip_atomic_load(&qclean[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          __hip_atomic_store(&qclean[m], clean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fin = clean >= rounds;
         }
         if (fin) {
           const int f = atomicAdd(&ctl->finished, 1);
@@ -890,12 +908,12 @@ static void osjq_launch(EigPlan* p, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB, upr = nb / 2;
   hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap);
   hipLaunchKernelGGL(osjq_reset_kernel, dim3(1), dim3(1), 0, st, p->qctl);
-  hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->batch, upr,
-                     p->rep);
+  hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->qclean,
+                     p->batch, upr, p->rep);
   long units = (long)p->batch * upr;
   const int grid = (int)(units < 512 ? units : 512);  // 2 resident workgroups per CU; fewer than that is fine too
   hipLaunchKernelGGL((osjq_kernel<RP>), dim3(grid), dim3(256), 0, st, p->Gc, p->ldn, nb, p->batch, p->sweeps, p->sort_from,
-                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone);
+                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone, p->qclean);
 }
 
 // orders <= 256: round 0 carries the pairs inside the blocks, nb - 1 launches per sweep
@@ -903,11 +921,12 @@ template <int RP>
 static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB;
   const int so = sweep >= p->sort_from ? 1 : 0;
+  const int rps = p->rps;  // nb - 1
   hipLaunchKernelGGL((osjw_kernel<RP, 8, true>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb, 0,
-                     p->notconv, sweep, p->trace, so, p->rep);
+                     p->notconv, sweep * rps, rps, p->trace, so, p->rep);
   for (int round = 1; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, 8, false>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb,
-                       round, p->notconv, sweep, p->trace, so, p->rep);
+                       round, p->notconv, sweep * rps + round, rps, p->trace, so, p->rep);
 }
 
 // G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
@@ -935,13 +954,20 @@ __global__ void osj_begin_kernel(const double* __restrict__ Gc, int ldn, int nfl
   for (int f = lane; f < nflag; f += 64) notconv[(long)f * gridDim.x + b] = 0;
 }
 
-// Profiling only: adds the number of (matrix, sweep) pairs that did work in the solve just finished
-// (every matrix runs sweep 0; matrix b runs sweep s > 0 iff sweep s - 1 raised its flag).
-__global__ void osj_count_kernel(const int* __restrict__ notconv, int batch, int sweeps, unsigned long long* __restrict__ acc,
-                                 const int* __restrict__ rep) {
+// Profiling only: adds the number of (matrix, launch round) pairs that did work in the solve just finished.
+__global__ void osj_count_kernel(const int* __restrict__ notconv, int batch, int nround, int rps,
+                                 unsigned long long* __restrict__ acc, const int* __restrict__ rep) {
+  // (matrix, launch round) pairs that did work: a round runs unless the rps rounds before it were all clean
   int c = 0;
-  for (long i = threadIdx.x; i < (long)batch * (sweeps - 1); i += blockDim.x) c += notconv[i] != 0;
-  for (int b = threadIdx.x; b < batch; b += blockDim.x) c += (!rep || rep[b] == b);  // sweep 0: every solved matrix
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+    if (rep && rep[b] != b) continue;
+    int clean = 0;
+    for (int r = 0; r < nround; ++r) {
+      if (r >= rps && clean >= rps) break;
+      ++c;
+      clean = notconv[(long)r * batch + b] ? 0 : clean + 1;
+    }
+  }
   c = (int)wave_sum((double)c);
   if ((threadIdx.x & 63) == 0) atomicAdd(acc, (unsigned long long)c);
 }
@@ -976,12 +1002,13 @@ template <int NT>
 static void osjw4_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   constexpr int RP = NT / 64;
   const int nb = p->ldn / OSJ_CB;
+  const int rps = p->rps;  // nb: the intra-block launch + nb - 1 block-pair rounds
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols, p->rep);
+                     2 * nb, 0, p->notconv, sweep * rps, rps, p->trace, p->sortcols, p->rep);
   const int so = sweep >= p->sort_from ? 1 : 0;
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, 4, false>), dim3(nb / 2, p->batch), dim3(512), 0, st, p->Gc, p->ldn, nb, round,
-                       p->notconv, sweep, p->trace, so, p->rep);
+                       p->notconv, sweep * rps + 1 + round, rps, p->trace, so, p->rep);
 }
 
 template <int NT>
@@ -993,11 +1020,12 @@ static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   // INTRA: pairs within each single block.  Run as MODE 2 on "super blocks" of 2*CB columns would also
   // rotate the cross pairs of (2b, 2b+1); instead launch MODE 2 with half-size blocks: CB/2 columns per
   // block -> 2*(CB/2) = CB columns per workgroup = exactly one block.
+  const int rps = p->rps;  // nb
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep, p->trace, p->sortcols, p->rep);
+                     2 * nb, 0, p->notconv, sweep * rps, rps, p->trace, p->sortcols, p->rep);
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, NT, 1>), dim3(nb / 2, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                       nb, round, p->notconv, sweep, p->trace, p->sortcols, p->rep);
+                       nb, round, p->notconv, sweep * rps + 1 + round, rps, p->trace, p->sortcols, p->rep);
 }
 
 static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
@@ -1075,6 +1103,10 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
       p->sortcols = 0;
     }
     {
+      const int nb0 = p->ldn / OSJ_CB;
+      p->rps = (p->wavek && p->ldn <= 256) ? (nb0 > 1 ? nb0 - 1 : 1) : nb0;
+    }
+    {
       // persistent work-queue solver: wave-private kernel orders (<= 256), at most 255 global rounds per solve
       // Default (MUSED_EIG_QUEUE unset): batches of at most 224 units per round (one sketch lane: 28 matrices x 4) --
       // the persistent workgroups then occupy at most one slot on fewer than all CUs, so kernels of other streams
@@ -1091,6 +1123,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         MUSED_CHECK_HIP(hipMalloc(&p->q, sizeof(unsigned) * (size_t)p->qcap));
         MUSED_CHECK_HIP(hipMalloc(&p->qctl, sizeof(OsjqCtl)));
         MUSED_CHECK_HIP(hipMalloc(&p->qdone, sizeof(int) * (size_t)batch));
+        MUSED_CHECK_HIP(hipMalloc(&p->qclean, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMemset(p->qctl, 0, sizeof(OsjqCtl)));
       }
     }
@@ -1100,7 +1133,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
     const char* ad = getenv("MUSED_EIG_ADAPTIVE");
     if (!(ad && ad[0] == '0') && !(flags & EIG_PLAN_FIXED_SWEEPS)) {
       // [trace (batch doubles) | work counter (1 x u64) | flags (batch * sweeps ints)]
-      MUSED_CHECK_HIP(hipMalloc(&p->trace, sizeof(double) * ((size_t)batch + 1) + sizeof(int) * (size_t)batch * sweeps));
+      MUSED_CHECK_HIP(hipMalloc(&p->trace, sizeof(double) * ((size_t)batch + 1) + sizeof(int) * (size_t)batch * sweeps * p->rps));
       p->work = (unsigned long long*)(p->trace + batch);
       p->notconv = (int*)(p->trace + batch + 1);
       MUSED_CHECK_HIP(hipMemset(p->work, 0, 8));
@@ -1145,6 +1178,7 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->q) (void)hipFree(p->q);
   if (p->qctl) (void)hipFree(p->qctl);
   if (p->qdone) (void)hipFree(p->qdone);
+  if (p->qclean) (void)hipFree(p->qclean);
   if (p->ev0) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
@@ -1190,14 +1224,15 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
   }
   const int nb = p->ldn / OSJ_CB;
   // per sweep: (nb - 1) block-pair rounds, plus one launch for the pairs inside the blocks in the row-per-thread kernel
-  *launches = (long)p->prof_n * p->sweeps * ((p->wavek && p->ldn <= 256) ? nb - 1 : nb);
+  *launches = (long)p->prof_n * p->sweeps * p->rps;
+  (void)nb;
   // a launch reads and writes every element of every matrix that is still iterating; with the adaptive sweep
   // count the launches of later sweeps find fewer (or no) such matrices: average over the launches timed
   double frac = 1.0;
   if (p->work && p->prof_n > 0) {
     unsigned long long w = 0;
     MUSED_CHECK_HIP(hipMemcpy(&w, p->work, 8, hipMemcpyDeviceToHost));
-    frac = (double)w / ((double)p->prof_n * p->sweeps * p->batch);
+    frac = (double)w / ((double)p->prof_n * p->sweeps * p->rps * p->batch);
   }
   *bytes_per_launch = 16.0 * (double)p->batch * p->ldn * p->ldn * frac;
   return MUSED_OK;
@@ -1232,7 +1267,8 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     if (!p->direct)
       hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc);
     if (p->notconv)
-      hipLaunchKernelGGL(osj_begin_kernel, dim3(p->batch), dim3(64), 0, st, p->Gc, p->ldn, p->sweeps, p->trace, p->notconv);
+      hipLaunchKernelGGL(osj_begin_kernel, dim3(p->batch), dim3(64), 0, st, p->Gc, p->ldn, p->sweeps * p->rps, p->trace,
+                         p->notconv);
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->have_graph && allow_graph) {
@@ -1245,7 +1281,8 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
       MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
       ++p->prof_n;
       if (p->notconv)
-        hipLaunchKernelGGL(osj_count_kernel, dim3(1), dim3(256), 0, st, p->notconv, p->batch, p->sweeps, p->work, p->rep);
+        hipLaunchKernelGGL(osj_count_kernel, dim3(1), dim3(256), 0, st, p->notconv, p->batch, p->sweeps * p->rps, p->rps,
+                           p->work, p->rep);
     }
     hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam);
     if (evals)
@@ -1285,12 +1322,12 @@ int mused_debug_osj_time(const double* init, int batch, int variant, int reps, d
   auto launch = [&](int round) {
     dim3 grid(nb / 2, batch), blk(256);
     switch (variant) {
-      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
-      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
-      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
-      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
-      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr); break;
-      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, (const double*)nullptr, 1, (const int*)nullptr);
+      case 5: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 5>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, 1, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 7: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 7>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, 1, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 2: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 2>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, 1, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 3: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 3>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, 1, (const double*)nullptr, 1, (const int*)nullptr); break;
+      case 4: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 4>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, 1, (const double*)nullptr, 1, (const int*)nullptr); break;
+      default: hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, 256, 1, 0>), grid, blk, 0, st, G, 256, ldn, nb, round, (int*)nullptr, 0, 1, (const double*)nullptr, 1, (const int*)nullptr);
     }
   };
   MUSED_CHECK_HIP(hipEventRecord(e0, st));
