@@ -74,6 +74,24 @@ long mused_knn_fused_ws_bytes(long n, int cap);
 int mused_knn_fused(const void* X, int dtype, long n, int d, long ld, int k, int metric, void* ws, long ws_bytes, int cap,
                     int* out_idx, unsigned long long* out_mask, int mask_words, int* overflow_out, void* stream);
 
+/* ---- a1, metadata modality types (/root/reference/matrix_operations.py:22-89) -----------------------
+ * Scores for mused_select_k_smallest (smaller = closer), all n x n fp64 with pitch n.
+ * mused_record_scores: rec = n x 2 fp64 records.  kind MUSED_REC_LOCATION: (latitude, longitude) in degrees ->
+ *   haversine distance in km, the arithmetic of haversine_distance (:250-263) operation by operation; replaces
+ *   NearestNeighbors(metric=haversine_distance).kneighbors (:29-30).  kind MUSED_REC_TIME: (datetaken, dateupload) ->
+ *   |d datetaken| + |d dateupload| (:40-50); replaces the per-row argsort loop (:39-54).
+ * mused_jaccard_scores: tag sets as CSR (rowptr[n + 1], tags[]: ids < n_tags, unique per row) plus the transposed
+ *   posting lists (postptr[n_tags + 1], postrow[]); S[i][j] = -|Ti & Tj| / |Ti | Tj| (0 if either set is empty,
+ *   jaccard_similarity :245-248), S[i][i] = +1 (the reference scores a row against itself with -1 and sorts
+ *   descending, :87-88).  n <= 65536.
+ * mused_group_mask: ids[n] (< 0: no user name) -> adjacency bitmask of "same id, other row" (:56-71, 123-130). */
+#define MUSED_REC_LOCATION 0
+#define MUSED_REC_TIME 1
+int mused_record_scores(const double* rec, int n, int kind, double* S, void* stream);
+int mused_jaccard_scores(const int* rowptr, const int* tags, const int* postptr, const int* postrow, int n, int n_tags,
+                         double* S, void* stream);
+int mused_group_mask(const int* ids, int n, unsigned long long* out_mask, int mask_words, void* stream);
+
 /* ---- a3 / a4: adjacency bitmasks -------------------------------------------------------------
  * An adjacency is n rows x words uint64 (words >= ceil(n/64)); bit j of row i <=> A[i][j] = 1. */
 

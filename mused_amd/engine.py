@@ -221,6 +221,51 @@ class WindowEngine:
         adj = Adjacency(mask, n)
         return (adj, idx) if want_idx else adj
 
+    # ---- a1, metadata modality types (csrc/meta.hip) ------------------------
+    def _select(self, n: int, kk: int) -> Adjacency:
+        w = words_for(n)
+        mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+        call("mused_select_k_smallest", ptr(self.scores), n, n, kk, None, ptr(mask), w, stream_ptr())
+        return Adjacency(mask, n)
+
+    def record_adjacency(self, records, kind: str, kk: int) -> Adjacency:
+        """The kk closest rows per row (self removed) of n x 2 records: kind "location" = haversine km between
+        (latitude, longitude) pairs (matrix_operations.py:22-31, 250-263), "time" = |d datetaken| + |d dateupload|
+        (:33-54).  Ties go to the smaller row index."""
+        rec = torch.as_tensor(np.ascontiguousarray(records, dtype=np.float64)).to(self.device)
+        n = rec.shape[0]
+        if n > self.n_max or rec.shape[1] != 2:
+            raise ValueError(f"{kind}: need (n <= {self.n_max}) x 2 records, got {tuple(rec.shape)}")
+        call("mused_record_scores", ptr(rec), n, {"location": 0, "time": 1}[kind], ptr(self.scores), stream_ptr())
+        return self._select(n, kk)
+
+    def jaccard_adjacency(self, rowptr, tags, n_tags: int, kk: int) -> Adjacency:
+        """The kk rows with the largest Jaccard similarity of tag sets per row (matrix_operations.py:73-89); sets as CSR
+        (int32 rowptr[n + 1], tags[]: ids < n_tags, unique inside a row).  Ties go to the smaller row index."""
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        tags = np.ascontiguousarray(tags, dtype=np.int32)
+        n = len(rowptr) - 1
+        if n > self.n_max:
+            raise ValueError(f"window of {n} rows exceeds the engine capacity {self.n_max}")
+        rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rowptr))
+        order = np.argsort(tags, kind="stable")  # posting lists: rows of a tag in ascending order
+        postrow = rows[order]
+        postptr = np.concatenate([[0], np.cumsum(np.bincount(tags, minlength=max(n_tags, 1)))]).astype(np.int32)
+        dev = [torch.from_numpy(a).to(self.device) for a in (rowptr, tags if len(tags) else np.zeros(1, np.int32),
+                                                              postptr, postrow if len(postrow) else np.zeros(1, np.int32))]
+        call("mused_jaccard_scores", ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), n, int(n_tags), ptr(self.scores),
+             stream_ptr())
+        return self._select(n, kk)
+
+    def group_adjacency(self, ids) -> Adjacency:
+        """A[i][j] = 1 iff ids[i] == ids[j] >= 0 and i != j (matrix_operations.py:56-71: same user name)."""
+        ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(self.device)
+        n = ids_d.numel()
+        w = words_for(n)
+        mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+        call("mused_group_mask", ptr(ids_d), n, ptr(mask), w, stream_ptr())
+        return Adjacency(mask, n)
+
     # ---- a3 / a4 ------------------------------------------------------------------------
     def fuse(self, adjs) -> Adjacency:
         n, w = adjs[0].n, adjs[0].words

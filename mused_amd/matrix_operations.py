@@ -22,8 +22,10 @@ Two call styles:
 modality_type "text" (matrix_operations.py:91-110) vectorises the ('title', 'description') strings on the
 host with the same scikit-learn TfidfVectorizer call as the reference and runs the cosine / top-(k+1)
 kernel on the device; already vectorised rows can use modality_type="cosine".
-Not on the device path: the other metadata modality types of the SED2012
-dataset ("location", "time", "username", "tags"): they raise NotImplementedError here.
+The metadata modality types of the SED2012 stream keep their string handling on the host and score /
+select on the device (csrc/meta.hip): "location" (haversine kNN, :22-31), "time" (:33-54), "username" (:56-71),
+"tags" (Jaccard, :73-89).  Where the reference's own choice between EQUAL scores is undefined (unstable argsort,
+ball-tree traversal) the smaller row index wins here.
 """
 from __future__ import annotations
 
@@ -35,13 +37,24 @@ _METADATA_TYPES = ("location", "time", "username", "tags")
 
 
 def _metric_for(modality_type) -> str:
+    """Similarity kernel of a DENSE modality type (the metadata types have their own scores)."""
     if modality_type in _METADATA_TYPES:
-        raise NotImplementedError(
-            f"modality_type={modality_type!r} works on SED2012 metadata columns (strings / two-column "
-            "records, matrix_operations.py:22-110) and is outside the device hot path; dense feature "
-            'rows use the default type (Euclidean kNN) or "cosine"'
-        )
+        raise ValueError(f"modality_type={modality_type!r} is a metadata type, not a dense-row metric")
     return "cosine" if modality_type in ("cosine", "text") else "l2"
+
+
+def edges_per_row(modality_type, k_basis):
+    """Upper bound of the ones a row of create_adjacency_matrix can hold, None when there is none ("username")."""
+    k = int(k_basis)
+    if modality_type == "username":
+        return None
+    if modality_type == "time":
+        return 3 * k + 1
+    if modality_type == "tags":
+        return max(k, 0)
+    if modality_type in ("location", "cosine", "text"):
+        return k + 1
+    return max(k, 1)
 
 
 def adjacency_on_device(data, modality_type="", k_basis=50, engine=None) -> _eng.Adjacency:
@@ -53,6 +66,8 @@ def adjacency_on_device(data, modality_type="", k_basis=50, engine=None) -> _eng
 
     if modality_type == "text":
         return _text_adjacency(data, k_basis, engine)
+    if modality_type in _METADATA_TYPES:
+        return _metadata_adjacency(data, modality_type, k_basis, engine)
     metric = _metric_for(modality_type)
     if isinstance(data, torch.Tensor):
         X = _eng.to_device_rows(data)
@@ -111,6 +126,49 @@ def _text_adjacency(data, k_basis, engine=None) -> _eng.Adjacency:
         return empty()
     V = np.asarray(TfidfVectorizer().fit_transform(text).todense(), dtype=np.float64)
     sub = eng.knn_adjacency(_eng.to_device_rows(V), k_basis, "cosine")
+    if len(valid) == n:
+        return sub
+    return _scatter_valid(sub, torch.from_numpy(valid).to(eng.device), n)
+
+
+def _metadata_adjacency(data, modality_type, k_basis, engine=None) -> _eng.Adjacency:
+    """matrix_operations.py:22-89.  Row validity, k and the string handling follow the reference branch by branch on
+    the host; scores and the selection run on the device."""
+    import torch
+
+    if isinstance(data, torch.Tensor):
+        data = data.cpu().numpy()
+    data = np.asarray(data)
+    n = len(data)
+    eng = engine or _eng.default_engine(max(n, 1))
+    empty = lambda: _eng.Adjacency(torch.zeros((n, _eng.words_for(n)), dtype=torch.int64, device=eng.device), n)
+    k = int(k_basis)
+    if modality_type == "location":  # 'latitude', 'longitude'; k + 1 because a row is its own nearest neighbour
+        valid = np.where(~np.isnan(data.astype(np.float64)).any(axis=1))[0]
+        if len(valid) == 0:
+            return empty()
+        sub = eng.record_adjacency(data[valid], "location", min(k + 1, len(valid)))
+    elif modality_type == "time":  # 'datetaken', 'dateupload'; 0.0 marks a missing stamp
+        valid = np.where(~((data[:, 0] == 0.0) | (data[:, 1] == 0.0)))[0]
+        if len(valid) == 0 or 3 * k + 1 <= 0:
+            return empty()
+        sub = eng.record_adjacency(data[valid], "time", min(3 * k + 1, len(valid)))
+    elif modality_type == "username":
+        valid = np.where(data[:, 0] != "")[0]
+        if len(valid) == 0:
+            return empty()
+        _, ids = np.unique(data[valid, 0].astype(str), return_inverse=True)
+        sub = eng.group_adjacency(ids)
+    else:  # "tags"
+        valid = np.where(data[:, 0] != "")[0]
+        if len(valid) == 0 or k <= 0:
+            return empty()
+        vocab, rowptr, ids = {}, [0], []
+        for tags in data[valid, 0]:
+            tag_set = set(tags) if tags else set()
+            ids.extend(sorted(vocab.setdefault(t, len(vocab)) for t in tag_set))
+            rowptr.append(len(ids))
+        sub = eng.jaccard_adjacency(rowptr, np.asarray(ids, dtype=np.int32), len(vocab), min(k, len(valid)))
     if len(valid) == n:
         return sub
     return _scatter_valid(sub, torch.from_numpy(valid).to(eng.device), n)

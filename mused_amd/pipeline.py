@@ -130,15 +130,19 @@ class StreamPipeline:
             reduced = B.t().contiguous() if B.shape[0] != self.W else B  # main.py:73-76
             return reduced, sigma, None
         # edges per row: k selected (l2; the row itself is normally one of them) or k + 1 (cosine / text)
-        nnz_cap = fused.n * sum(max(self.k, 1) + (0 if mo._metric_for(t) == "l2" else 1) for t in types)
+        per_row = [mo.edges_per_row(t, self.k) for t in types]
+        if any(b is None for b in per_row):  # "username": as many edges as a user has rows -> count them (blocking)
+            nnz_cap = max(int(fused.degrees()[2][1].item()), 1)
+        else:
+            nnz_cap = fused.n * sum(per_row)
         emb, sigma, flags = self.eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap, want_flags=True)
         return emb, sigma, flags
 
     def _adjacency(self, m, t):
         """One modality of one window -> device adjacency, with the reference's row filtering."""
-        if t == "text" or not isinstance(m, torch.Tensor):
+        if t == "text" or t in mo._METADATA_TYPES or not isinstance(m, torch.Tensor):
             return mo.adjacency_on_device(m, t, self.k, engine=self.eng)
-        metric = mo._metric_for(t)  # raises for the metadata types that are not on the device path
+        metric = mo._metric_for(t)
         if not self.assume_finite and m.is_floating_point():
             if self._chk is None:
                 self._chk = torch.cuda.Stream()

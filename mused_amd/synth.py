@@ -80,6 +80,43 @@ def text_stream(n: int, seed: int = 0, vocab: int = 120, topics: int = 4, blank_
     return data.astype(str), labels.astype(np.int64)
 
 
+def metadata_stream(n: int, seed: int = 0, events: int = 5, users: int = 24, vocab: int = 60, missing: float = 0.05,
+                    integer_time: bool = False):
+    """Synthetic SED2012-style metadata columns, in the layout data_loader.py:87-99 hands to the reference:
+        location (n, 2) float64  latitude, longitude in degrees, NaN where the photo has no geotag
+        time     (n, 2) float64  datetaken, dateupload in seconds, 0.0 = missing stamp (matrix_operations.py:36)
+        username (n, 1) str      '' = missing
+        tags     (n, 1) object   list of str per row ([] = no tags)
+    Every row belongs to one of `events` events: a place, a time span, a crowd of users and a tag distribution.
+    Time stamps carry random fractions of a second unless integer_time (then equal differences -- ties -- are common).
+    Returns (dict of arrays, event labels)."""
+    rng = np.random.default_rng([seed, 0x3E7A])
+    labels = rng.integers(0, events, size=n)
+    centre = np.stack([rng.uniform(35.0, 60.0, events), rng.uniform(-10.0, 30.0, events)], axis=1)
+    loc = centre[labels] + rng.normal(0.0, 0.05, size=(n, 2))
+    loc[rng.random(n) < missing] = np.nan
+    t0 = rng.uniform(1.2e9, 1.3e9, events)
+    taken = t0[labels] + rng.uniform(0.0, 3 * 86400.0, n)
+    upload = taken + rng.exponential(5 * 86400.0, n)
+    time = np.stack([taken, upload], axis=1)
+    if integer_time:
+        time = np.floor(time / 3600.0) * 3600.0
+    time[rng.random(n) < missing, 0] = 0.0
+    time[rng.random(n) < missing, 1] = 0.0
+    crowd = [rng.choice(users, size=max(3, users // events), replace=False) for _ in range(events)]
+    user = np.array([[f"user{int(rng.choice(crowd[e])):03d}"] for e in labels], dtype=object)
+    user[rng.random(n) < missing, 0] = ""
+    words = [f"tag{i:02d}" for i in range(vocab)]
+    dist = [0.3 * np.full(vocab, 1.0 / vocab) + 0.7 * rng.dirichlet(np.full(vocab, 0.1)) for _ in range(events)]
+    tags = np.empty((n, 1), dtype=object)
+    for i in range(n):
+        m = int(rng.integers(0, 8))
+        if rng.random() < missing:
+            m = 0
+        tags[i, 0] = [words[j] for j in rng.choice(vocab, size=m, p=dist[labels[i]])]  # repeats allowed: set() dedupes
+    return {"location": loc, "time": time, "username": user.astype(str), "tags": tags}, labels.astype(np.int64)
+
+
 STREAMS = {"gauss": gauss_stream, "blob": blob_stream, "fd": fd_stream}
 
 

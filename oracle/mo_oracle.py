@@ -125,12 +125,66 @@ def text_vectors(data):
     return valid, np.asarray(TfidfVectorizer().fit_transform(text).todense(), dtype=np.float64)
 
 
+def haversine_scores(rec):
+    """matrix_operations.py:250-263 for every pair of (latitude, longitude) rows, evaluated with the `math` functions the
+    reference calls, operation by operation (pure-Python double loop: small cases only)."""
+    from math import asin, cos, radians, sin, sqrt
+
+    n = len(rec)
+    S = np.zeros((n, n))
+    rad = [(radians(float(a)), radians(float(b))) for a, b in rec]
+    for i, (lat1, lon1) in enumerate(rad):
+        for j, (lat2, lon2) in enumerate(rad):
+            dlat = lat2 - lat1
+            dlon = lon2 - lon1
+            a = sin(dlat / 2) ** 2 + cos(lat1) * cos(lat2) * sin(dlon / 2) ** 2
+            S[i, j] = 2 * asin(sqrt(a)) * 6371
+    return S
+
+
+def time_scores(rec):
+    """matrix_operations.py:40-50: |datetaken_j - datetaken_i| + |dateupload_j - dateupload_i|."""
+    rec = np.asarray(rec, dtype=np.float64)
+    return np.abs(rec[None, :, 0] - rec[:, None, 0]) + np.abs(rec[None, :, 1] - rec[:, None, 1])
+
+
+def jaccard_scores(tag_column):
+    """matrix_operations.py:80-88 + jaccard_similarity (:245-248), negated so that smaller = more similar; a row
+    scores +1 against itself (the reference gives it similarity -1 and sorts descending)."""
+    sets = [set(t) if t else set() for t in tag_column]
+    n = len(sets)
+    S = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                S[i, j] = 1.0
+            elif sets[i] and sets[j]:
+                S[i, j] = 0.0 - len(sets[i] & sets[j]) / len(sets[i] | sets[j])
+    return S
+
+
+def metadata_scores(data, modality_type, k_basis):
+    """(valid row indices, score matrix among them (smaller = closer) or None, number of rows selected per row) of the
+    metadata branches "location" (:22-31), "time" (:33-54), "tags" (:73-89)."""
+    data = np.asarray(data)
+    if modality_type == "location":
+        valid = np.where(~np.isnan(data.astype(np.float64)).any(axis=1))[0]
+        return valid, (haversine_scores(data[valid].astype(np.float64)) if len(valid) else None), k_basis + 1
+    if modality_type == "time":
+        valid = np.where(~((data[:, 0] == 0.0) | (data[:, 1] == 0.0)))[0]
+        return valid, (time_scores(data[valid]) if len(valid) else None), 3 * k_basis + 1
+    if modality_type == "tags":
+        valid = np.where(data[:, 0] != "")[0]
+        return valid, (jaccard_scores(data[valid, 0]) if len(valid) else None), k_basis
+    raise ValueError(modality_type)
+
+
 def create_adjacency_matrix(data, modality_type, k_basis=50):
     """matrix_operations.py:14-20,112-132 for the dense numeric `case _`
     (any modality_type the reference does not special-case), the `text`
-    branch (:91-110: TF-IDF + cosine + top-(k+1)) and a dense "cosine" type
+    branch (:91-110: TF-IDF + cosine + top-(k+1)), a dense "cosine" type
     (the cosine kernel of that branch, :106-108, applied to already-vectorised
-    rows).
+    rows) and the metadata branches "location", "time", "username", "tags" (:22-89).
 
     Returns the (n, n) float64 0/1 matrix: A[i, j] = 1 iff j is among the
     selected neighbours of i and j != i (directed; :123-130).
@@ -142,6 +196,22 @@ def create_adjacency_matrix(data, modality_type, k_basis=50):
         valid, V = text_vectors(data)
         if len(valid) and V.shape[1]:
             mask = _select_k_smallest_mask(cosine_scores(V), min(k_basis + 1, len(valid)))
+            np.fill_diagonal(mask, False)
+            A[np.ix_(valid, valid)] = mask
+        return A
+    if modality_type == "username":  # :56-71: every other row of the same (non-empty) user name
+        valid = np.where(data[:, 0] != "")[0]
+        names = data[valid, 0]
+        mask = names[:, None] == names[None, :]
+        np.fill_diagonal(mask, False)
+        A[np.ix_(valid, valid)] = mask
+        return A
+    if modality_type in ("location", "time", "tags"):
+        # the k closest rows; where the reference's pick between EQUAL scores is undefined (unstable argsort :53,88,
+        # ball-tree traversal :30) the smaller row index wins, as in _select_k_smallest_mask
+        valid, S, kk = metadata_scores(data, modality_type, k_basis)
+        if S is not None and kk > 0:
+            mask = _select_k_smallest_mask(S, min(kk, len(valid)))
             np.fill_diagonal(mask, False)
             A[np.ix_(valid, valid)] = mask
         return A

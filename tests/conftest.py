@@ -77,6 +77,41 @@ def text_inputs(g):
     return data, labels, n, k
 
 
+METADATA_TYPES = ("location", "time", "username", "tags")
+# reference picks that are decided by its unstable argsort between EQUAL scores (matrix_operations.py:53, 88): every
+# "tags" adjacency (most Jaccard similarities are 0) and the "time" adjacency of the whole-hour stream B
+METADATA_TIE_CASES = {("A", "tags"), ("B", "tags"), ("B", "time")}
+
+
+def metadata_inputs(g, tag):
+    """Regenerate stream A / B of tests/golden/metadata.npz: (columns dict, labels, n, k)."""
+    from mused_amd import synth
+
+    n, k, seed, integer_time = (int(x) for x in g[f"{tag}_meta"])
+    cols, labels = synth.metadata_stream(n, seed, integer_time=bool(integer_time))
+    return cols, labels, n, k
+
+
+def metadata_reference_adjacency(g, tag, t, n):
+    return np.unpackbits(g[f"{tag}_{t}_bits"], axis=1)[:, :n]
+
+
+def assert_valid_topk(A, valid, S, kk):
+    """A (0/1, window coordinates) is A valid answer to "the kk smallest scores of every row of S, self removed":
+    everything strictly below the kk-th smallest score is selected, nothing above it is, and the count is right.
+    This is all the reference defines when scores tie (its argsort is unstable)."""
+    kk = min(kk, len(valid))
+    sub = np.asarray(A)[np.ix_(valid, valid)].astype(bool)
+    other = ~np.eye(len(valid), dtype=bool)
+    thr = np.partition(S, kk - 1, axis=1)[:, kk - 1][:, None]
+    assert not ((S < thr) & ~sub & other).any()      # nothing closer was left out
+    assert not (sub & (S > thr)).any()               # nothing farther was taken
+    self_in = (np.diag(S)[:, None] < thr).ravel() | ((np.diag(S)[:, None] == thr).ravel() & (sub.sum(1) == kk - 1))
+    assert np.array_equal(sub.sum(1) + self_in, np.full(len(valid), kk))
+    rest = np.setdiff1d(np.arange(len(A)), valid)
+    assert not np.asarray(A)[rest].any() and not np.asarray(A)[:, rest].any()
+
+
 COSINE_DENSE_CASES = [("gauss", 500, 64, 0, 10), ("gauss", 500, 64, 0, 50), ("blob", 700, 96, 1, 10), ("blob", 700, 96, 1, 50)]
 
 

@@ -213,6 +213,69 @@ def case_bench_stream(tag, kind, n_windows, W, d, ell, k, seed):
          labels=allc.astype(np.int8), cumulative_sha16=np.array(cum))
 
 
+def case_metadata():
+    """the metadata branches of create_adjacency_matrix (matrix_operations.py:22-89) on synthetic
+    SED2012-style columns (mused_amd.synth.metadata_stream), through the reference's own function.  Stored per type: the
+    adjacency bits (np.packbits).  Stream A (seed 0) has fractional time stamps; stream B (seed 1) whole hours, where the
+    reference's unstable argsort decides between equal differences.  Plus one fused window (location OR username OR
+    text) through fuse_matrices / perform_svd_reduction / perform_clustering, and a whole run of the reference's
+    window loop over the (location, username) columns."""
+    out = {}
+    n, k = 300, 8
+    for tag, seed, integer_time in (("A", 0, False), ("B", 1, True)):
+        cols, labels = synth.metadata_stream(n, seed, integer_time=integer_time)
+        for t in ("location", "time", "username", "tags"):
+            A = quiet(ref_mo.create_adjacency_matrix, cols[t], t, k)
+            out[f"{tag}_{t}_bits"] = np.packbits(A.astype(bool), axis=1)
+            out[f"{tag}_{t}_hash"] = np.array(nbr_hash(A))
+        out[f"{tag}_meta"] = np.array([n, k, seed, int(integer_time)])
+    # degenerate inputs: nothing valid -> no edges; fewer valid rows than k
+    out["none_location"] = quiet(ref_mo.create_adjacency_matrix, np.full((4, 2), np.nan), "location", 2).astype(np.uint8)
+    out["none_time"] = quiet(ref_mo.create_adjacency_matrix, np.zeros((4, 2)), "time", 2).astype(np.uint8)
+    out["none_user"] = quiet(ref_mo.create_adjacency_matrix, np.array([[""]] * 4), "username", 2).astype(np.uint8)
+    few, _ = synth.metadata_stream(6, 2, missing=0.0)
+    for t in ("location", "time", "username", "tags"):
+        out[f"few_{t}"] = quiet(ref_mo.create_adjacency_matrix, few[t], t, 8).astype(np.uint8)
+    # fused window + eigenstep + labels
+    n, k, ell, seed = 400, 10, 12, 0
+    cols, labels = synth.metadata_stream(n, 3)
+    text, _ = synth.text_stream(n, 3)
+    types_ = ["location", "username", "text"]
+    mods = [cols["location"], cols["username"], text]
+    adjs = [quiet(ref_mo.create_adjacency_matrix, m, t, k) for m, t in zip(mods, types_)]
+    fused = ref_mo.fuse_matrices(adjs)
+    svd = TruncatedSVD(n_components=min(ell, fused.shape[1] - 1), random_state=seed)
+    emb = svd.fit_transform(fused)
+    assert np.array_equal(emb, ref_mo.perform_svd_reduction(fused, ell, seed))
+    km = quiet(ref_mo.perform_clustering, emb, len(np.unique(labels)), seed)
+    out["win_meta"] = np.array([n, k, ell, seed, 3])
+    out["win_adj_hash"] = np.array([nbr_hash(a) for a in adjs])
+    out["win_fused_hash"] = np.array(nbr_hash(fused))
+    out["win_R"] = np.array(float(np.max(np.linalg.norm(fused, axis=1) ** 2)))
+    out["win_sigma"] = svd.singular_values_
+    out["win_labels"] = km.astype(np.int32)
+    # whole run: (location, username) through main.py's loop
+    n, W, ell, k, seed = 1200, 300, 8, 8, 0
+    cols, labels = synth.metadata_stream(n, 4)
+    captured = {}
+
+    def fake_metrics(results, subset_size, noise_rate, label_mode, sorting, reduced_dim, k_basis,
+                     window_size, clusters, true_labels, t1, t0):
+        captured["clusters"] = np.asarray(clusters).copy()
+        return results
+
+    orig = ref_me.compute_all_metrics
+    ref_me.compute_all_metrics = fake_metrics
+    try:
+        quiet(ref_main.process_streaming_data, {}, [cols["location"], cols["username"]], ["location", "username"], W, ell,
+              k, len(np.unique(labels)), seed, "sSVDMC", labels, 1, 0.0, "types", False, 1.5, 2)
+    finally:
+        ref_me.compute_all_metrics = orig
+    out["run_meta"] = np.array([n, W, ell, k, seed, 4])
+    out["run_clusters"] = captured["clusters"].astype(np.int64)
+    save("metadata", **out)
+
+
 def case_edges():
     """Small edge cases of create_adjacency_matrix / fuse / match_clusters."""
     rng = np.random.default_rng(7)
@@ -271,6 +334,8 @@ def main():
     if only:
         if "cosine" in only:
             case_cosine()
+        if "metadata" in only:
+            case_metadata()
         if "c1_stream_hop2_blob_s0" in only:   # hopping windows (step_window_ratio = 2, main.py:32)
             case_stream("c1_stream_hop2_blob_s0", "blob", 3000, 64, 500, 16, 50, 0, ratio=2, n_centres=4, sep=2.0)
             case_stream("c1_stream_hop4_gauss_s1", "gauss", 2000, 64, 400, 16, 30, 1, ratio=4)
@@ -283,6 +348,7 @@ def main():
         return
     case_edges()
     case_cosine()
+    case_metadata()
     # BASELINE config 1 shapes: n=5000, d=64, W=500, ell=16, k=50
     for seed in (0, 1):
         case_windows(f"c1_gauss_s{seed}", "gauss", 1500, 64, 500, 16, 50, seed)

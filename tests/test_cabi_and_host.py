@@ -83,15 +83,18 @@ def test_host_consumers_match_reference_goldens():
     A = np.arange(12.0).reshape(3, 4)
     F = mo.fuse_matrices([A])  # single modality: plain float64 copy (matrix_operations.py:135)
     assert F is not A and F.dtype == np.float64 and np.array_equal(F, A)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception):  # metadata types run on the device too: no CPU fallback without one
         mo.adjacency_on_device(np.zeros((4, 2)), "location", 2)
 
 
-def test_metadata_modalities_are_refused_not_silently_mishandled():
+def test_modality_types_map_to_their_own_kernels():
     from mused_amd import matrix_operations as mo
 
     for t in ("location", "time", "username", "tags"):
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(ValueError):  # never silently treated as dense Euclidean rows
             mo._metric_for(t)
     assert mo._metric_for("") == "l2" and mo._metric_for("anything") == "l2" and mo._metric_for("cosine") == "cosine"
     assert mo._metric_for("text") == "cosine"  # host TF-IDF + the device cosine kernel (matrix_operations.py:91-110)
+    # edges a row can hold, per type (matrix_operations.py:25, 35, 74, 93, 113): sizes the CSR of the eigenstep
+    assert [mo.edges_per_row(t, 50) for t in ("", "cosine", "text", "location", "time", "tags", "username")] == \
+        [50, 51, 51, 51, 151, 50, None]

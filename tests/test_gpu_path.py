@@ -3,7 +3,8 @@ oracle and the committed golden vectors (which come from the reference's own mod
 import numpy as np
 import pytest
 
-from conftest import COSINE_DENSE_CASES, cosine_dense_inputs, load_golden, nbr_hash, regen_inputs, text_inputs
+from conftest import (COSINE_DENSE_CASES, METADATA_TIE_CASES, METADATA_TYPES, assert_valid_topk, cosine_dense_inputs,
+                      load_golden, metadata_inputs, metadata_reference_adjacency, nbr_hash, regen_inputs, text_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -92,9 +93,73 @@ def test_text_modality_matches_reference_golden(eng):
     assert A.dtype == np.float64 and A.shape == (n, n)
     assert nbr_hash(A) == str(g["text_adj_hash"])
     assert np.array_equal(mo.create_adjacency_matrix(np.array([["", ""]] * 4), "text", 2).astype(np.uint8), g["blank_A"])
-    for t in ("location", "time", "username", "tags"):
-        with pytest.raises(NotImplementedError):
-            mo.create_adjacency_matrix(np.zeros((4, 2)), t, 2)
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+@pytest.mark.parametrize("t", METADATA_TYPES)
+def test_metadata_branches_match_reference_and_oracle(tag, t):
+    """SURVEY 8 f4 (matrix_operations.py:22-89): "location", "username" and the fractional-second "time" stream equal
+    the reference's adjacency bit for bit; "tags" and whole-hour "time" (the reference's unstable argsort picks between
+    equal scores there) equal the oracle (ties to the smaller row) and the reference's answer is a valid top-k of the
+    same scores."""
+    from mused_amd import matrix_operations as mo
+    from oracle import mo_oracle as omo
+
+    g = load_golden("metadata")
+    cols, _, n, k = metadata_inputs(g, tag)
+    A = mo.create_adjacency_matrix(cols[t], t, k)
+    assert A.dtype == np.float64 and A.shape == (n, n)
+    assert np.array_equal(A, omo.create_adjacency_matrix(cols[t], t, k))
+    if (tag, t) not in METADATA_TIE_CASES:
+        assert np.array_equal(A.astype(np.uint8), metadata_reference_adjacency(g, tag, t, n))
+        assert nbr_hash(A) == str(g[f"{tag}_{t}_hash"])
+    elif t != "username":
+        valid, S, kk = omo.metadata_scores(cols[t], t, k)
+        assert_valid_topk(A, valid, S, kk)
+
+
+def test_metadata_degenerate_inputs_and_window_golden():
+    from mused_amd import matrix_operations as mo
+    from mused_amd import synth
+
+    g = load_golden("metadata")
+    assert np.array_equal(mo.create_adjacency_matrix(np.full((4, 2), np.nan), "location", 2), g["none_location"])
+    assert np.array_equal(mo.create_adjacency_matrix(np.zeros((4, 2)), "time", 2), g["none_time"])
+    assert np.array_equal(mo.create_adjacency_matrix(np.array([[""]] * 4), "username", 2), g["none_user"])
+    few, _ = synth.metadata_stream(6, 2, missing=0.0)  # fewer valid rows than k
+    for t in METADATA_TYPES:
+        assert np.array_equal(mo.create_adjacency_matrix(few[t], t, 8).astype(np.uint8), g[f"few_{t}"])
+    # fused (location OR username OR text) window: adjacency hashes, R, sigma, k-means labels of the reference
+    n, k, ell, seed, sseed = (int(x) for x in g["win_meta"])
+    cols, labels = synth.metadata_stream(n, sseed)
+    text, _ = synth.text_stream(n, sseed)
+    types_ = ["location", "username", "text"]
+    adjs = [mo.adjacency_on_device(m, t, k) for m, t in zip([cols["location"], cols["username"], text], types_)]
+    assert [nbr_hash(a.to_numpy()) for a in adjs] == [str(h) for h in g["win_adj_hash"]]
+    fused = mo.fuse_matrices(adjs)
+    assert nbr_hash(fused.to_numpy()) == str(g["win_fused_hash"]) and mo.max_row_sq_norm(fused) == float(g["win_R"])
+    emb, sigma = mo.svd_reduce_on_device(fused, ell, seed)
+    np.testing.assert_allclose(sigma.cpu().numpy(), g["win_sigma"], rtol=1e-8)
+    km = mo.perform_clustering(emb.cpu().numpy(), len(np.unique(labels)), seed)
+    assert np.array_equal(km, g["win_labels"])
+
+
+def test_metadata_scores_at_window_size():
+    """n = 2,500 rows (a quarter window; the oracle's haversine is a Python double loop): device adjacency == oracle for
+    every metadata type, and the same-user relation has no degree bound (its CSR is sized from the real edge count)."""
+    from mused_amd import matrix_operations as mo
+    from mused_amd import synth
+    from oracle import mo_oracle as omo
+
+    n, k = 2500, 50
+    cols, _ = synth.metadata_stream(n, 11, events=12, users=40)
+    for t in METADATA_TYPES:
+        A = mo.create_adjacency_matrix(cols[t], t, k)
+        assert np.array_equal(A, omo.create_adjacency_matrix(cols[t], t, k)), t
+    adj = mo.adjacency_on_device(cols["username"], "username", k)
+    assert int(adj.degrees()[2][0].item()) > 3 * k + 1  # a busy user has more neighbours than any k-limited type
+    emb, sigma = mo.svd_reduce_on_device(adj, 16, 0)  # nnz cap defaults to the real edge count
+    assert np.isfinite(sigma.cpu().numpy()).all()
 
 
 @pytest.mark.parametrize("name", WINDOW_CASES)

@@ -66,8 +66,8 @@ def test_process_streaming_data_signature_and_hopping_windows():
 
 def test_stream_with_nonfinite_rows_and_modality_types():
     """The drop-in window loop filters non-finite rows like the reference (matrix_operations.py:114-115), runs the
-    "text" modality (host TF-IDF + device cosine) next to a numeric one, and refuses the metadata modality types that
-    are not on the device path instead of silently treating them as Euclidean rows."""
+    "text" modality (host TF-IDF + device cosine) next to a numeric one, and the five SED2012 modality types together
+    (data_loader.py:113) with labels equal to the CPU oracle's window loop."""
     from mused_amd import synth
     from mused_amd.pipeline import process_streaming_data
     from oracle import mo_oracle as omo
@@ -85,9 +85,27 @@ def test_stream_with_nonfinite_rows_and_modality_types():
     res = process_streaming_data({}, [Xn, text], ["", "text"], 300, 6, 15, 4, 0, "sSVDMC", tl, 1, 0.0, "types", False, 1.5, 2)
     ref = omo.process_streaming_data([Xn, text], ["", "text"], 300, 6, 15, 0, "sSVDMC", tl)
     assert np.array_equal(res["all_clusters"], ref)
-    for t in ("location", "time", "username", "tags"):
-        with pytest.raises(NotImplementedError):
-            process_streaming_data({}, [X], [t], 300, 6, 15, 3, 0, "sSVDMC", labels, 1, 0.0, "types", False, 1.5, 2)
+    cols, ml = synth.metadata_stream(900, 7)
+    text, _ = synth.text_stream(900, 7)
+    mods = [cols["location"], cols["time"], cols["username"], cols["tags"], text]
+    types_ = ["location", "time", "username", "tags", "text"]
+    res = process_streaming_data({}, mods, types_, 300, 8, 8, 5, 0, "sSVDMC", ml, 1, 0.0, "types", False, 1.5, 2)
+    ref = omo.process_streaming_data(mods, types_, 300, 8, 8, 0, "sSVDMC", ml)
+    assert np.array_equal(res["all_clusters"], ref)
+
+
+def test_metadata_run_matches_reference_golden():
+    """Whole run of the reference's window loop over the (location, username) columns (tests/golden/metadata.npz)."""
+    from conftest import load_golden
+    from mused_amd import synth
+    from mused_amd.pipeline import process_streaming_data
+
+    g = load_golden("metadata")
+    n, W, ell, k, seed, sseed = (int(x) for x in g["run_meta"])
+    cols, labels = synth.metadata_stream(n, sseed)
+    res = process_streaming_data({}, [cols["location"], cols["username"]], ["location", "username"], W, ell, k,
+                                 len(np.unique(labels)), seed, "sSVDMC", labels, 1, 0.0, "types", False, 1.5, 2)
+    assert np.array_equal(np.asarray(res["all_clusters"], dtype=np.int64), g["run_clusters"])
 
 
 def test_swfdmc_approach_matches_oracle_pipeline():

@@ -5,7 +5,9 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import COSINE_DENSE_CASES, cosine_dense_inputs, load_golden, nbr_hash, regen_inputs, text_inputs
+from conftest import (COSINE_DENSE_CASES, METADATA_TIE_CASES, METADATA_TYPES, assert_valid_topk, cosine_dense_inputs,
+                      load_golden, metadata_inputs, metadata_reference_adjacency, nbr_hash, regen_inputs, text_inputs)
+from mused_amd import synth
 from oracle import mo_oracle as mo
 
 WINDOW_CASES = ["c1_gauss_s0", "c1_gauss_s1", "c1_blob_s0", "c1_blob_s1", "c1_fd_s0", "c4s_twomod_s0"]
@@ -91,6 +93,60 @@ def test_cosine_kernel_matches_reference_arithmetic(tag, n, d, seed, k):
     X = cosine_dense_inputs(g, tag, n, d, seed, k)
     A = mo.create_adjacency_matrix(X.astype(np.float64), "cosine", k)
     assert nbr_hash(A) == str(g[f"dense_{tag}_k{k}_hash"])
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+@pytest.mark.parametrize("t", METADATA_TYPES)
+def test_metadata_branches_match_reference(tag, t):
+    """the reference's "location" / "time" / "username" / "tags" branches (matrix_operations.py:22-89) on
+    synthetic SED2012-style columns.  Bit-equal adjacency wherever the reference's choice is defined; where it is decided
+    by an unstable argsort between equal scores, the reference's adjacency must be A valid top-k of the oracle's scores
+    (and so is the oracle's own, which breaks ties towards the smaller row)."""
+    g = load_golden("metadata")
+    cols, _, n, k = metadata_inputs(g, tag)
+    A_ref = metadata_reference_adjacency(g, tag, t, n)
+    A = mo.create_adjacency_matrix(cols[t], t, k)
+    if (tag, t) not in METADATA_TIE_CASES:
+        assert np.array_equal(A.astype(np.uint8), A_ref)
+        assert nbr_hash(A) == str(g[f"{tag}_{t}_hash"])
+    else:
+        assert not np.array_equal(A.astype(np.uint8), A_ref)  # if this ever holds, move the case to the exact list
+    if t != "username":
+        valid, S, kk = mo.metadata_scores(cols[t], t, k)
+        assert_valid_topk(A_ref, valid, S, kk)
+        assert_valid_topk(A, valid, S, kk)
+
+
+def test_metadata_degenerate_inputs():
+    g = load_golden("metadata")
+    assert np.array_equal(mo.create_adjacency_matrix(np.full((4, 2), np.nan), "location", 2), g["none_location"])
+    assert np.array_equal(mo.create_adjacency_matrix(np.zeros((4, 2)), "time", 2), g["none_time"])
+    assert np.array_equal(mo.create_adjacency_matrix(np.array([[""]] * 4), "username", 2), g["none_user"])
+    few, _ = synth.metadata_stream(6, 2, missing=0.0)  # fewer valid rows than k
+    for t in METADATA_TYPES:
+        assert np.array_equal(mo.create_adjacency_matrix(few[t], t, 8).astype(np.uint8), g[f"few_{t}"])
+
+
+def test_metadata_window_and_run_match_reference():
+    """Fused (location OR username OR text) window through the eigenstep and k-means, and a whole run of the window
+    loop over (location, username): hashes, sigma, labels as the reference produced them."""
+    g = load_golden("metadata")
+    n, k, ell, seed, sseed = (int(x) for x in g["win_meta"])
+    cols, labels = synth.metadata_stream(n, sseed)
+    text, _ = synth.text_stream(n, sseed)
+    types_ = ["location", "username", "text"]
+    adjs = [mo.create_adjacency_matrix(m, t, k) for m, t in zip([cols["location"], cols["username"], text], types_)]
+    assert [nbr_hash(a) for a in adjs] == [str(h) for h in g["win_adj_hash"]]
+    fused = mo.fuse_matrices(adjs)
+    assert nbr_hash(fused) == str(g["win_fused_hash"]) and mo.max_row_sq_norm(fused) == float(g["win_R"])
+    emb, sigma, _ = mo.randomized_svd_reduce(fused, ell, seed)
+    np.testing.assert_allclose(sigma, g["win_sigma"], rtol=1e-10)
+    assert np.array_equal(mo.perform_clustering(emb, len(np.unique(labels)), seed), g["win_labels"])
+    n, W, ell, k, seed, sseed = (int(x) for x in g["run_meta"])
+    cols, labels = synth.metadata_stream(n, sseed)
+    out = mo.process_streaming_data([cols["location"], cols["username"]], ["location", "username"], W, ell, k, seed,
+                                    "sSVDMC", labels)
+    assert np.array_equal(out, g["run_clusters"])
 
 
 def test_edges():
