@@ -330,8 +330,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __r
 static int select_launch(const double* S, long ld, int n, int k, int* out_idx, unsigned long long* out_mask,
                          int mask_words, hipStream_t stream) {
   const size_t lds = (n <= SEL_MAX_LDS_KEYS) ? (size_t)n * 8 : 0;
-  MUSED_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_k_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SEL_MAX_LDS_KEYS * 8));
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(select_k_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_MAX_LDS_KEYS * 8);
+  });
+  MUSED_CHECK_HIP(attr_rc);
   hipLaunchKernelGGL(select_k_kernel, dim3(n), dim3(SEL_THREADS), lds, stream, S, ld, n, k, out_idx, out_mask,
                      mask_words);
   MUSED_LAUNCH_CHECK();

@@ -4,6 +4,8 @@
 // :56-71).  The k smallest scores per row are then taken by mused_select_k_smallest (ties to the smaller column; the
 // reference's own tie order is that of an unstable sort / a tree traversal and is not defined).  All of this is small
 // HBM-bound work next to the dense modalities: one pass that writes n x n scores (or n x n / 64 mask words).
+#include <mutex>
+
 #include "common.h"
 #include "internal.h"
 
@@ -127,12 +129,13 @@ int mused_jaccard_scores(const int* rowptr, const int* tags, const int* postptr,
   // a set has < 65536 tags (16-bit intersection counters) and the counters of one row fit the 160 KB of LDS
   MUSED_REQUIRE(n <= 65536, "mused_jaccard_scores: at most 65536 rows per window (n=%d)", n);
   const size_t lds = (size_t)n * sizeof(unsigned short);
-  static int lds_set = 0;
-  if (lds > 64 * 1024 && lds > (size_t)lds_set) {
-    MUSED_CHECK_HIP(hipFuncSetAttribute((const void*)jaccard_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        128 * 1024));
-    lds_set = 128 * 1024;
-  }
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)jaccard_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  128 * 1024);
+  });
+  MUSED_CHECK_HIP(attr_rc);
   jaccard_scores_kernel<<<n, 256, lds, (hipStream_t)stream>>>(rowptr, tags, postptr, postrow, n, S);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
