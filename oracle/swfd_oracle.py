@@ -43,7 +43,8 @@ Specification (every free constant of Appendix A fixed here)
   that would still be inside the window (dropped_t + N <= now or nothing
   dropped; top level if none), stack its in-window snapshots, its K and the
   pending rows, one more shrink:  B = sqrt(max(lam - lam[ell-1], 0))[:ell] Vt[:ell]
-  zero-padded to (ell, d); every row's largest-magnitude entry made positive.
+  (rows with shrunk energy <= 1e-10 * lam_0 set to zero, as in a rotation: they are below what a Gram-based
+  implementation resolves) zero-padded to (ell, d); every row's largest-magnitude entry made positive.
   Returns (B, sigma = row norms of B, level, delta).
 """
 from __future__ import annotations
@@ -181,9 +182,10 @@ class SeqBasedSWFD:
     def get(self):
         j = self.select_level()
         M = self.stacked(j)
-        s2, Vt, _, delta = _shrink(M, self.ell)
+        s2, Vt, lam0, delta = _shrink(M, self.ell)
         B = np.zeros((self.ell, self.d))
         if len(s2):
+            s2 = np.where(s2 > REL_TOL * lam0, s2, 0.0)  # the discard rule of the rotation, applied to the query too
             B[: len(s2)] = np.sqrt(s2)[:, None] * Vt
         idx = np.argmax(np.abs(B), axis=1)
         sg = np.sign(B[np.arange(self.ell), idx])
