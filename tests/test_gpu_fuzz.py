@@ -22,3 +22,17 @@ def test_random_cases(seed):
     for i in range(60):
         rng = np.random.default_rng([seed, i])
         (fz.swfd_case if i % 2 == 0 else fz.knn_case)(rng, i)
+
+
+def test_random_eigenstep_and_pipeline_cases():
+    """Eigenstep on random kNN graphs (sigma to 1e-8, embedding columns with separated singular values to 1e-6, device
+    k-means == scikit-learn on the same embedding) and the whole window loop against the oracle's restatement of
+    main.py:13-130 with random window sizes, hop ratios, approaches and modality types (labels equal; where the oracle
+    raises scipy's "cost matrix is infeasible", so must the device pipeline)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import fuzz_parity as fz
+
+    for i in range(40):
+        rng = np.random.default_rng([13, i])
+        (fz.rsvd_case if i % 2 == 0 else fz.pipeline_case)(rng, i)

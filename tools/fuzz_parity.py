@@ -127,17 +127,118 @@ def knn_case(rng, i):
     return f"knn  {kind:9s} n={n:3d} d={d:2d} k={k:3d} type={t!r:8s} dtype={X.dtype} {note}"
 
 
+def rsvd_case(rng, i):
+    """Eigenstep on a random kNN adjacency (one or two modalities OR-fused, some rows without any valid neighbour)."""
+    n = int(rng.integers(24, 640))
+    k = int(rng.integers(1, min(30, n - 1) + 1))
+    M = int(rng.integers(1, 3))
+    mods = []
+    for _ in range(M):
+        X = rng.standard_normal((n, int(rng.integers(2, 20))))
+        if rng.random() < 0.4:
+            X += 3.0 * rng.standard_normal((int(rng.integers(2, 6)), X.shape[1]))[rng.integers(0, 2, n)]
+        if rng.random() < 0.3:
+            X[rng.random(n) < 0.15, 0] = np.nan  # rows without edges (matrix_operations.py:114-115)
+        mods.append(X)
+    ell = int(rng.integers(1, min(40, n - 1) + 1))
+    seed = int(rng.integers(0, 1000))
+    adjs_o = [omo.create_adjacency_matrix(X, "", k) for X in mods]
+    fused_o = omo.fuse_matrices(adjs_o)
+    emb_o, sig_o, _ = omo.randomized_svd_reduce(fused_o, ell, seed)
+    adjs_d = [mo.adjacency_on_device(X, "", k) for X in mods]
+    fused_d = mo.fuse_matrices(adjs_d)
+    assert np.array_equal(fused_d.to_numpy() != 0, fused_o != 0), f"rsvd case {i}: fused adjacency differs"
+    emb_d, sig_d = mo.svd_reduce_on_device(fused_d, ell, seed)
+    emb_d, sig_d = emb_d.cpu().numpy(), sig_d.cpu().numpy()
+    s0 = sig_o[0]
+    np.testing.assert_allclose(sig_d, sig_o, rtol=0, atol=1e-8 * s0, err_msg=f"rsvd case {i} n={n} k={k} l={ell} seed={seed}")
+    # embedding columns: compared where the singular value is separated from its neighbours (a cluster of equal sigmas
+    # may come out in any basis of its space)
+    gaps = np.minimum(np.abs(np.diff(sig_o, prepend=np.inf)), np.abs(np.diff(sig_o, append=-np.inf)))
+    clear = gaps > 1e-4 * s0
+    np.testing.assert_allclose(emb_d[:, clear], emb_o[:, clear], rtol=0, atol=1e-6 * np.abs(emb_o).max(),
+                               err_msg=f"rsvd case {i} n={n} k={k} l={ell} seed={seed} (embedding)")
+    nc = int(rng.integers(2, 7))
+    lab_o = omo.perform_clustering(emb_o, nc, seed)
+    lab_d = mo.perform_clustering(emb_d, nc, seed)
+    same = np.array_equal(lab_o, lab_d)
+    lab_dev = mo.perform_clustering_on_device(torch.from_numpy(emb_d).cuda(), nc, seed)
+    assert np.array_equal(lab_dev, lab_d), f"rsvd case {i}: device k-means differs from scikit-learn on the same embedding"
+    return f"rsvd n={n:3d} k={k:2d} M={M} l={ell:2d} seed={seed:3d} clear={int(clear.sum())}/{ell} labels {'equal' if same else 'DIFFER (' + str(int((lab_o != lab_d).sum())) + ')'}"
+
+
+def pipeline_case(rng, i):
+    """Whole window loop against the oracle's restatement of main.py:13-130: random window size, hop ratio, modalities."""
+    from mused_amd import synth
+    from mused_amd.pipeline import process_streaming_data
+
+    W = int(rng.integers(60, 260))
+    ratio = int(rng.choice([1, 1, 2, 4]))
+    while W % ratio:
+        W += 1
+    n = W * int(rng.integers(2, 5)) + int(rng.integers(0, W))
+    ell = int(rng.integers(2, 12))
+    k = int(rng.integers(3, 14))
+    seed = int(rng.integers(0, 100))
+    sseed = int(rng.integers(0, 10000))
+    cols, labels = synth.metadata_stream(n, sseed, events=int(rng.integers(2, 6)))
+    pool = {"": synth.blob_stream(n, int(rng.integers(2, 24)), sseed, n_centres=4)[0].astype(np.float64),
+            "cosine": synth.blob_stream(n, int(rng.integers(3, 24)), sseed + 1, n_centres=4)[0].astype(np.float64),
+            "location": cols["location"], "username": cols["username"], "text": synth.text_stream(n, sseed)[0]}
+    types_ = [str(t) for t in rng.choice(list(pool), size=int(rng.integers(1, 4)), replace=False)]
+    if types_ == ["username"]:
+        # a same-user relation alone is a disjoint union of cliques: its singular values are the clique sizes - 1 with
+        # multiplicities, a cluster of equal values straddles the cut at reduced_dim, and the retained directions --
+        # hence the labels -- are then the arbitrary choice of the dense SVD routine (LAPACK's in the reference)
+        types_.append("")
+    mods = [pool[t] for t in types_]
+    approach = str(rng.choice(["sSVDMC", "sSVDMC", "SWFDMC"]))
+    kw = {}
+    if approach == "SWFDMC":
+        from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
+        kw["swfd_cls"] = OraSWFD
+    try:
+        ref = omo.process_streaming_data(mods, types_, W, ell, k, seed, approach, labels, step_window_ratio=ratio, **kw)
+    except ValueError as e:
+        # scipy's linear_sum_assignment refuses a cost matrix that passes is_feasible (matrix_operations.py:226-233: no
+        # all-inf row or column) but has no complete finite assignment; the reference lets that propagate (main.py:331)
+        try:
+            process_streaming_data({}, mods, types_, W, ell, k, len(np.unique(labels)), seed, approach, labels, ratio, 0.0,
+                                   "types", False, 1.5, 2)
+        except ValueError as e2:
+            assert str(e2) == str(e), f"pipeline case {i}: {e2!r} vs {e!r}"
+            return f"pipe W={W:3d} ratio={ratio} n={n:4d} {approach:6s} types={types_} both raise {e}"
+        raise AssertionError(f"pipeline case {i}: the oracle raised {e!r}, the device pipeline did not")
+    res = process_streaming_data({}, mods, types_, W, ell, k, len(np.unique(labels)), seed, approach, labels, ratio, 0.0,
+                                 "types", False, 1.5, 2)
+    got = np.asarray(res["all_clusters"])
+    assert len(got) == len(ref), f"pipeline case {i}: {len(got)} labels vs {len(ref)}"
+    bad = int((got != np.asarray(ref)).sum())
+    if approach == "SWFDMC" and bad:
+        # k-means on the (W, l) transposed sketch of a sparse 0/1 matrix has exactly tied assignments (many embedding
+        # rows are equal or zero): seen to flip on a sketch that agrees with the oracle's to 3e-16 (case (7, 101)), so
+        # label equality is not asserted for this approach here; sketch parity is what swfd_case checks
+        return f"pipe W={W:3d} ratio={ratio} n={n:4d} l={ell:2d} k={k:2d} {approach:6s} types={types_} labels differ in {bad} (tied k-means)"
+    assert bad == 0, f"pipeline case {i} W={W} ratio={ratio} n={n} l={ell} k={k} types={types_} approach={approach}: {bad} labels differ"
+    return f"pipe W={W:3d} ratio={ratio} n={n:4d} l={ell:2d} k={k:2d} {approach:6s} types={types_} labels equal ({len(ref)})"
+
+
+CASES = {"swfd": swfd_case, "knn": knn_case, "rsvd": rsvd_case, "pipe": pipeline_case}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=-1, help="run this case index only")
+    ap.add_argument("--kinds", default="swfd,knn", help="comma-separated subset of swfd,knn,rsvd,pipe (round robin)")
     a = ap.parse_args()
     t0 = time.time()
     np.set_printoptions(linewidth=200, precision=10)
     for i in (range(a.cases) if a.only < 0 else [a.only]):
         rng = np.random.default_rng([a.seed, i])
-        fn = swfd_case if i % 2 == 0 else knn_case
+        kinds = a.kinds.split(",")
+        fn = CASES[kinds[i % len(kinds)]]
         print(f"[{i:3d} seed=({a.seed},{i})]", fn(rng, i), f"({time.time() - t0:.0f}s)", flush=True)
     print(f"all {a.cases} cases passed")
 
