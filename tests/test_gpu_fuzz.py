@@ -36,3 +36,15 @@ def test_random_eigenstep_and_pipeline_cases():
     for i in range(40):
         rng = np.random.default_rng([13, i])
         (fz.rsvd_case if i % 2 == 0 else fz.pipeline_case)(rng, i)
+
+
+def test_random_lanes_and_metadata_cases():
+    """Lock-step lanes (incl. twin lanes) == independent sketches bit for bit and == the oracle; metadata modality
+    types on random columns (duplicate geotags / time stamps, everything missing, k = 0) == the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import fuzz_parity as fz
+
+    for i in range(40):
+        rng = np.random.default_rng([14, i])
+        (fz.lanes_case if i % 2 == 0 else fz.meta_case)(rng, i)

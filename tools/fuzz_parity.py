@@ -127,6 +127,84 @@ def knn_case(rng, i):
     return f"knn  {kind:9s} n={n:3d} d={d:2d} k={k:3d} type={t!r:8s} dtype={X.dtype} {note}"
 
 
+def lanes_case(rng, i):
+    """B lock-step lanes (some of them fed IDENTICAL rows: the duplicate-skipping path) == B independent sketches bit
+    for bit, and == the oracle within the SWFD tolerance."""
+    ell = int(rng.integers(2, 20))
+    N = int(rng.integers(max(ell + 1, 8), 300))
+    d = int(rng.integers(2, 70))
+    B = int(rng.integers(2, 7))
+    n = int(rng.integers(N // 2, 2 * N + 40))
+    dt = rng.choice([np.float32, np.float64])
+    Xs = [rng.standard_normal((n, d)) * rng.uniform(0.5, 8) for _ in range(B)]
+    for b in range(1, B):
+        if rng.random() < 0.3:
+            Xs[b] = Xs[int(rng.integers(0, b))]  # twin lanes
+        elif rng.random() < 0.3:
+            Xs[b] = (rng.random((n, d)) < 0.2).astype(np.float64)
+    Xs = [x.astype(dt) for x in Xs]
+    R = max(max(float((x.astype(np.float64) ** 2).sum(1).max()) for x in Xs), 1.0)
+    lanes = Dev(N=N, R=R, d=d, sketch_dim=ell, lanes=B)
+    singles = [Dev(N=N, R=R, d=d, sketch_dim=ell) for _ in range(B)]
+    oras = [Ora(N=N, R=R, d=d, sketch_dim=ell) for _ in range(B)]
+    X = torch.from_numpy(np.stack(Xs)).cuda()
+    t = 0
+    checks = 0
+    while t < n:
+        step = int(rng.choice([1, ell, ell + 1, N - 1, N, N + 1, int(rng.integers(1, 2 * N))]))
+        step = max(1, min(step, n - t))
+        lanes.fit_lanes(X[:, t:t + step])
+        for b in range(B):
+            singles[b].fit(X[b, t:t + step])
+            oras[b].fit(Xs[b][t:t + step].astype(np.float64))
+        t += step
+        if rng.random() < 0.5 or t == n:
+            Bl, sl, ll, dl = lanes.get()
+            for b in range(B):
+                Bs, ss, ls, ds = singles[b].get()
+                tag = f"lanes case {i} N={N} d={d} l={ell} B={B} lane={b} t={t}"
+                assert int(ll[b]) == ls and np.array_equal(Bl[b], Bs) and np.array_equal(sl[b], ss) and dl[b] == ds, tag
+                compare(singles[b], oras[b], tag)
+            checks += 1
+    lanes.close()
+    for sk in singles:
+        sk.close()
+    return f"lanes N={N:3d} d={d:2d} l={ell:2d} B={B} rows={n:3d} dtype={np.dtype(dt).name} checks={checks}"
+
+
+def meta_case(rng, i):
+    """Metadata modality types (matrix_operations.py:22-89) on random synthetic columns: device == oracle."""
+    from mused_amd import synth
+
+    n = int(rng.integers(2, 420))
+    k = int(rng.integers(0, 40))
+    cols, _ = synth.metadata_stream(n, int(rng.integers(0, 1 << 30)), events=int(rng.integers(1, 8)),
+                                    users=int(rng.integers(3, 60)), vocab=int(rng.integers(8, 80)),
+                                    missing=float(rng.choice([0.0, 0.05, 0.5, 1.0])), integer_time=bool(rng.random() < 0.5))
+    if rng.random() < 0.3:  # duplicate geotags / stamps
+        src = rng.integers(0, n, n // 2)
+        dst = rng.integers(0, n, n // 2)
+        cols["location"][dst] = cols["location"][src]
+        cols["time"][dst] = cols["time"][src]
+    out = []
+    for t in ("location", "time", "username", "tags"):
+        ref = omo.create_adjacency_matrix(cols[t], t, k)
+        got = mo.create_adjacency_matrix(cols[t], t, k)
+        if t == "location" and not np.array_equal(got, ref):
+            # sin / cos / asin differ in the last bit between the device and the host libm: entries may move between
+            # rows' selections only where two haversine distances agree to rounding
+            valid, S, kk = omo.metadata_scores(cols[t], t, k)
+            thr = np.partition(S, min(kk, len(valid)) - 1, axis=1)[:, min(kk, len(valid)) - 1][:, None]
+            diff = (got != ref)[np.ix_(valid, valid)]
+            assert (np.abs(S - thr)[diff] <= 1e-9 * np.maximum(thr, 1e-3).repeat(S.shape[1], 1)[diff]).all(), \
+                f"meta case {i} location n={n} k={k}: differs beyond rounding of the haversine distance"
+            out.append(f"location~{int(diff.sum())}")
+            continue
+        assert np.array_equal(got, ref), f"meta case {i} type={t} n={n} k={k}: {int((got != ref).sum())} entries differ"
+        out.append(t)
+    return f"meta n={n:3d} k={k:2d} " + " ".join(out)
+
+
 def rsvd_case(rng, i):
     """Eigenstep on a random kNN adjacency (one or two modalities OR-fused, some rows without any valid neighbour)."""
     n = int(rng.integers(24, 640))
@@ -223,7 +301,7 @@ def pipeline_case(rng, i):
     return f"pipe W={W:3d} ratio={ratio} n={n:4d} l={ell:2d} k={k:2d} {approach:6s} types={types_} labels equal ({len(ref)})"
 
 
-CASES = {"swfd": swfd_case, "knn": knn_case, "rsvd": rsvd_case, "pipe": pipeline_case}
+CASES = {"swfd": swfd_case, "knn": knn_case, "rsvd": rsvd_case, "pipe": pipeline_case, "lanes": lanes_case, "meta": meta_case}
 
 
 def main():
@@ -231,7 +309,7 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=-1, help="run this case index only")
-    ap.add_argument("--kinds", default="swfd,knn", help="comma-separated subset of swfd,knn,rsvd,pipe (round robin)")
+    ap.add_argument("--kinds", default="swfd,knn", help="comma-separated subset of swfd,knn,rsvd,pipe,lanes,meta (round robin)")
     a = ap.parse_args()
     t0 = time.time()
     np.set_printoptions(linewidth=200, precision=10)
