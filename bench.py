@@ -312,7 +312,9 @@ def main():
     st_main = torch.cuda.Stream(priority=-1 if hi_main else 0)
     st_sketch = [torch.cuda.Stream(priority=0 if hi_main else -1) for _ in sketches]
     pipe = StreamPipeline(W, ell, k, args.seed, "sSVDMC", modality_types=[""] * M, feature_sketch=False,
-                          async_labels=True, stream=st_main, assume_finite=True)
+                          async_labels=True, stream=st_main, assume_finite=True,
+                          # without the sketch the main path has the GPU to itself: overlap consecutive windows
+                          window_slots=int(os.environ.get("MUSED_WINDOW_SLOTS", "4")) if args.no_swfd else 1)
     torch.cuda.synchronize()
 
     import threading

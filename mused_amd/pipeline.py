@@ -33,7 +33,7 @@ from .swfd import SeqBasedSWFD
 class StreamPipeline:
     def __init__(self, window_size, reduced_dim, k_basis, seed, approach="sSVDMC", modality_types=None,
                  step_window_ratio=1, engine=None, async_labels=True, feature_sketch=False, stream=None,
-                 assume_finite=False):
+                 assume_finite=False, window_slots=1):
         if approach not in ("sSVDMC", "sSVDMC_hung", "SWFDMC"):
             raise ValueError(f"approach {approach!r} is not on the device hot path")
         self.W, self.ell, self.k, self.seed = int(window_size), int(reduced_dim), int(k_basis), int(seed)
@@ -46,6 +46,16 @@ class StreamPipeline:
         self._chk = None
         self.ratio = step_window_ratio
         self.eng = engine or WindowEngine(self.W)
+        # WINDOW SLOTS (sSVDMC only): adjacency -> fusion -> eigenstep of one window is a chain of ~1,600 small dependent
+        # launches that leaves most of the GPU idle (25 ms of latency, a few per cent of its throughput); windows are
+        # independent until the label chain, so consecutive windows go to `window_slots` engines on their own streams
+        # and overlap.  Measured at config 2: 29 -> 21.5 ms per window with 4 or more slots (340 k -> 460 k rows/s), where
+        # the ONE host thread that launches the 1,600-node graphs becomes the limit; 2 slots are slower than one (37 ms).
+        # Opt-in (default 1; MUSED_WINDOW_SLOTS for process_streaming_data).  The sketch approaches carry state from
+        # window to window and keep one slot.
+        self._nslots = max(1, int(window_slots)) if (approach != "SWFDMC" and not feature_sketch) else 1
+        self._slots = None        # [(engine, stream)], built at the first window
+        self._nwin = 0
         self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)
         self.feature_sketch = feature_sketch
         self.fswfd = None         # optional SWFD over the raw feature rows (BASELINE config 2 wording)
@@ -98,12 +108,13 @@ class StreamPipeline:
         self._device = torch.cuda.current_device()  # worker threads must select it themselves
 
     # ---- device side of one window --------------------------------------------------------------
-    def window_device(self, mods):
+    def window_device(self, mods, eng=None):
         """mods: list of (W, d_m) float32/float64 tensors on the device.  Returns (reduced (W, m) CUDA
         tensor, sigma CUDA tensor)."""
+        eng = eng or self.eng
         types = self.types or [""] * len(mods)
-        adjs = [self._adjacency(m, t) for m, t in zip(mods, types)]
-        fused = self.eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
+        adjs = [self._adjacency(m, t, eng) for m, t in zip(mods, types)]
+        fused = eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
         if len(adjs) == 1:
             fused.fused = False
         if self.feature_sketch:
@@ -135,13 +146,14 @@ class StreamPipeline:
             nnz_cap = max(int(fused.degrees()[2][1].item()), 1)
         else:
             nnz_cap = fused.n * sum(per_row)
-        emb, sigma, flags = self.eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap, want_flags=True)
+        emb, sigma, flags = eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap, want_flags=True)
         return emb, sigma, flags
 
-    def _adjacency(self, m, t):
+    def _adjacency(self, m, t, eng=None):
         """One modality of one window -> device adjacency, with the reference's row filtering."""
+        eng = eng or self.eng
         if t == "text" or t in mo._METADATA_TYPES or not isinstance(m, torch.Tensor):
-            return mo.adjacency_on_device(m, t, self.k, engine=self.eng)
+            return mo.adjacency_on_device(m, t, self.k, engine=eng)
         metric = mo._metric_for(t)
         if not self.assume_finite and m.is_floating_point():
             if self._chk is None:
@@ -151,8 +163,8 @@ class StreamPipeline:
             with torch.cuda.stream(self._chk):
                 ok = bool(torch.isfinite(m).all().item())
             if not ok:
-                return mo.adjacency_on_device(m, t, self.k, engine=self.eng)
-        return self.eng.knn_adjacency(m, self.k, metric)
+                return mo.adjacency_on_device(m, t, self.k, engine=eng)
+        return eng.knn_adjacency(m, self.k, metric)
 
     # ---- host consumers -------------------------------------------------------------------------
     def _cluster(self, job):
@@ -208,8 +220,27 @@ class StreamPipeline:
     def process_window(self, mods, true_labels_window, trigger=None):
         t_start = time.perf_counter()
         n_clusters = len(np.unique(true_labels_window))  # main.py:41
-        with torch.cuda.stream(self._stream if self._stream is not None else torch.cuda.current_stream()):
-            reduced, sigma, flags = self.window_device(mods)
+        caller = torch.cuda.current_stream()
+        if self._slots is None:
+            first = self._stream if self._stream is not None else caller
+            if self._nslots == 1:
+                self._slots = [(self.eng, self._stream)]  # stream None: whatever is current at each call
+            else:
+                # every slot on a stream of its own (none of them the caller's: a slot then waits for the caller's stream --
+                # whatever produced the rows -- without waiting for another slot's window)
+                self._slots = [(self.eng if i == 0 else WindowEngine(self.W), torch.cuda.Stream(priority=first.priority))
+                               for i in range(self._nslots)]
+        eng, st = self._slots[self._nwin % self._nslots]
+        st = st if st is not None else caller
+        self._nwin += 1
+        if self._nslots > 1:
+            st.wait_stream(caller)
+        with torch.cuda.stream(st):
+            if self._nslots > 1:
+                for m in mods:
+                    if isinstance(m, torch.Tensor):
+                        m.record_stream(st)
+            reduced, sigma, flags = self.window_device(mods, eng)
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
             red_pin, sig_pin = self._get_pins(reduced, sigma)
@@ -259,6 +290,9 @@ class StreamPipeline:
         for s in (self.swfd, self.fswfd):
             if s is not None:
                 s.close()
+        for e, _ in (self._slots or [])[1:]:
+            e.close()
+        self._slots = None
         for lim in (self._blas_limit, self._omp_limit):
             if lim is not None:
                 lim.restore_original_limits()
@@ -274,7 +308,8 @@ def process_streaming_data(results, data_modalities, modality_types, window_size
     t0 = time.time_ns()
     # modality types go through unchanged: "" / anything the reference does not special-case = Euclidean kNN
     # (matrix_operations.py:112), "text" and "cosine" = the cosine kernel, the other SED2012 metadata types raise
-    pipe = StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, list(modality_types), step_window_ratio)
+    pipe = StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, list(modality_types), step_window_ratio,
+                          window_slots=int(os.environ.get("MUSED_WINDOW_SLOTS", "1")))
     clusters = pipe.run(data_modalities, np.asarray(complete_true_labels))
     pipe.close()
     results = dict(results or {})

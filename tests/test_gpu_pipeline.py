@@ -94,6 +94,29 @@ def test_stream_with_nonfinite_rows_and_modality_types():
     assert np.array_equal(res["all_clusters"], ref)
 
 
+def test_window_slots_reproduce_the_reference_labels():
+    """Consecutive windows on several engines / streams (window_slots) -- the label chain still sees them in order."""
+    from conftest import load_golden, regen_inputs
+    from mused_amd.pipeline import StreamPipeline
+
+    g = load_golden("c1_stream_blob_s0")
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    for slots in (2, 3):
+        pipe = StreamPipeline(W, ell, k, seed, "sSVDMC", modality_types=[""], window_slots=slots)
+        out = pipe.run([m.astype(np.float64) for m in mods], labels)
+        pipe.close()
+        assert np.array_equal(np.asarray(out, dtype=np.int64), g["all_clusters"])
+    g = load_golden("metadata")  # string / metadata modality types through the slots as well
+    n, W, ell, k, seed, sseed = (int(x) for x in g["run_meta"])
+    from mused_amd import synth
+
+    cols, labels = synth.metadata_stream(n, sseed)
+    pipe = StreamPipeline(W, ell, k, seed, "sSVDMC", modality_types=["location", "username"], window_slots=3)
+    out = pipe.run([cols["location"], cols["username"]], labels)
+    pipe.close()
+    assert np.array_equal(np.asarray(out, dtype=np.int64), g["run_clusters"])
+
+
 def test_metadata_run_matches_reference_golden():
     """Whole run of the reference's window loop over the (location, username) columns (tests/golden/metadata.npz)."""
     from conftest import load_golden
