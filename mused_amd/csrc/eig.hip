@@ -8,6 +8,11 @@
 
 namespace mused {
 
+std::mutex& capture_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 struct OsjqCtl {
   unsigned head, tail;  // tickets handed to consumers / slots handed to producers
   int finished, nmat;   // matrices whose solve has ended / matrices that take part (representatives)
@@ -1143,6 +1148,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
   const char* ng = getenv("MUSED_NO_GRAPH");
   if (own_graph && !(ng && ng[0] == '1')) {
     MUSED_CHECK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+    std::lock_guard<std::mutex> capture_guard(capture_mutex());
     MUSED_CHECK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
     const int rc = osj_enqueue_sweeps(p, p->cap_stream);
     hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph);

@@ -2,7 +2,13 @@
 #pragma once
 #include "common.h"
 
+#include <mutex>
+
 namespace mused {
+
+// hipGraph stream captures of this library are serialised across host threads (see pipeline.py: window slots)
+std::mutex& capture_mutex();
+
 
 // C[z] = alpha * opA(A[z]) * opB(B[z]); fp64 in / fp64 out, MFMA f64 16x16x4.
 //   a_kc: A stored [M][K] (true) or [K][M] (false);  b_kc: B stored [N][K] (true) or [K][N] (false).

@@ -286,6 +286,7 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
       rsvd_drop_graph(h);
       // the capture stream lives only while it records: every live HIP stream competes for the hardware queues
       if (!h->cap_stream) MUSED_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+      std::lock_guard<std::mutex> capture_guard(capture_mutex());  // one capture at a time in the process
       MUSED_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
       rc = rsvd_enqueue(h, n, r, n_comp, n_iter, h->cap_stream, true);
       hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);

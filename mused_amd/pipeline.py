@@ -49,10 +49,10 @@ class StreamPipeline:
         # WINDOW SLOTS (sSVDMC only): adjacency -> fusion -> eigenstep of one window is a chain of ~1,600 small dependent
         # launches that leaves most of the GPU idle (25 ms of latency, a few per cent of its throughput); windows are
         # independent until the label chain, so consecutive windows go to `window_slots` engines on their own streams
-        # and overlap.  Measured at config 2: 29 -> 21.5 ms per window with 4 or more slots (340 k -> 460 k rows/s), where
-        # the ONE host thread that launches the 1,600-node graphs becomes the limit; 2 slots are slower than one (37 ms).
-        # Opt-in (default 1; MUSED_WINDOW_SLOTS for process_streaming_data).  The sketch approaches carry state from
-        # window to window and keep one slot.
+        # (each driven by its own host thread: launching the 1,600-node graph costs ~20 ms of host time) and overlap.
+        # Measured at config 2: 29 -> 15.6 ms per window with 6 slots (340 k -> 640 k rows/s); 2 slots are slower than
+        # one (37-40 ms), 4 vary between runs (hardware-queue sharing).  Opt-in (default 1; MUSED_WINDOW_SLOTS for
+        # process_streaming_data).  The sketch approaches carry state from window to window and keep one slot.
         self._nslots = max(1, int(window_slots)) if (approach != "SWFDMC" and not feature_sketch) else 1
         self._slots = None        # [(engine, stream)], built at the first window
         self._nwin = 0
@@ -105,6 +105,8 @@ class StreamPipeline:
         # would serialise concurrent pipelines
         self._pins = []
         self._flag_pins = []
+        self._pin_lock = threading.Lock()
+        self._dpools = None
         self._device = torch.cuda.current_device()  # worker threads must select it themselves
 
     # ---- device side of one window --------------------------------------------------------------
@@ -175,9 +177,11 @@ class StreamPipeline:
         ev.synchronize()
         reduced_host, sigma_host = red_pin.numpy().copy(), sig_pin.numpy().copy()
         flags_host = flag_pin.numpy().copy() if flag_pin is not None else None
-        self._pins.append((red_pin, sig_pin))
-        if flag_pin is not None:
-            self._flag_pins.append(flag_pin)
+        with self._pin_lock:
+            self._pins.append((red_pin, sig_pin))
+            if flag_pin is not None:
+                self._flag_pins.append(flag_pin)
+        if flags_host is not None:
             WindowEngine.check_rsvd_flags(flags_host)  # raised on the label worker, surfaces in flush()
         t0 = time.perf_counter()
         if self._km_device and reduced_dev is not None and reduced_dev.dtype == torch.float64:
@@ -208,33 +212,21 @@ class StreamPipeline:
 
     def _get_pins(self, reduced, sigma):
         while True:
-            for i, (rp, sp) in enumerate(self._pins):
-                if rp.shape == reduced.shape and sp.shape == sigma.shape:
-                    return self._pins.pop(i)
-            if len(self._pending) >= self._max_inflight:  # back-pressure: reuse a buffer instead of growing the pool
+            with self._pin_lock:
+                for i, (rp, sp) in enumerate(self._pins):
+                    if rp.shape == reduced.shape and sp.shape == sigma.shape:
+                        return self._pins.pop(i)
+            if self._nslots == 1 and len(self._pending) >= self._max_inflight:  # back-pressure: reuse a buffer
                 self._pending.popleft().result()
                 continue
             return (torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True),
                     torch.empty(sigma.shape, dtype=sigma.dtype, pin_memory=True))
 
-    def process_window(self, mods, true_labels_window, trigger=None):
-        t_start = time.perf_counter()
-        n_clusters = len(np.unique(true_labels_window))  # main.py:41
-        caller = torch.cuda.current_stream()
-        if self._slots is None:
-            first = self._stream if self._stream is not None else caller
-            if self._nslots == 1:
-                self._slots = [(self.eng, self._stream)]  # stream None: whatever is current at each call
-            else:
-                # every slot on a stream of its own (none of them the caller's: a slot then waits for the caller's stream --
-                # whatever produced the rows -- without waiting for another slot's window)
-                self._slots = [(self.eng if i == 0 else WindowEngine(self.W), torch.cuda.Stream(priority=first.priority))
-                               for i in range(self._nslots)]
-        eng, st = self._slots[self._nwin % self._nslots]
-        st = st if st is not None else caller
-        self._nwin += 1
-        if self._nslots > 1:
-            st.wait_stream(caller)
+    def _device_side(self, mods, n_clusters, trigger, t_start, eng, st, wait_ev):
+        """Enqueue one window on (eng, st); returns the job the label workers consume."""
+        torch.cuda.set_device(self._device)
+        if wait_ev is not None:
+            st.wait_event(wait_ev)  # whatever produced the rows on the caller's stream
         with torch.cuda.stream(st):
             if self._nslots > 1:
                 for m in mods:
@@ -248,15 +240,64 @@ class StreamPipeline:
             sig_pin.copy_(sigma, non_blocking=True)
             flag_pin = None
             if flags is not None:
-                flag_pin = self._flag_pins.pop() if self._flag_pins else torch.empty(4, dtype=torch.int32, pin_memory=True)
+                with self._pin_lock:
+                    flag_pin = self._flag_pins.pop() if self._flag_pins else None
+                if flag_pin is None:
+                    flag_pin = torch.empty(4, dtype=torch.int32, pin_memory=True)
                 flag_pin.copy_(flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced)
-        if self._pool is None:
-            self._chain(self._cluster(job), job)
-        else:
-            self._pending.append(self._pool.submit(self._chain, self._kpool.submit(self._cluster, job), job))
+        return (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced)
+
+    def _cluster_after(self, fut_job):
+        return self._cluster(fut_job.result())
+
+    def _chain_after(self, fut_cluster, fut_job):
+        return self._chain(fut_cluster, fut_job.result())
+
+    def process_window(self, mods, true_labels_window, trigger=None):
+        t_start = time.perf_counter()
+        n_clusters = len(np.unique(true_labels_window))  # main.py:41
+        caller = torch.cuda.current_stream()
+        if self._slots is None:
+            first = self._stream if self._stream is not None else caller
+            if self._nslots == 1:
+                self._slots = [(self.eng, self._stream)]  # stream None: whatever is current at each call
+            else:
+                # every slot on a stream of its own (none of them the caller's: a slot then waits for the caller's stream --
+                # whatever produced the rows -- without waiting for another slot's window) and with a host thread of its
+                # own: launching the ~1,600-node eigenstep graph costs ~20 ms of host time per window
+                self._slots = [(self.eng if i == 0 else WindowEngine(self.W), torch.cuda.Stream(priority=first.priority))
+                               for i in range(self._nslots)]
+                self._dpools = [ThreadPoolExecutor(max_workers=1) for _ in range(self._nslots)]
+                # Every engine records its eigenstep graph at its first window.  Do that here, one engine after the other
+                # and before any worker thread exists: a stream capture that overlaps HIP calls of other host threads
+                # (allocations, launches) has failed with "operation failed due to a previous error during capture".
+                for e_, s_ in self._slots:
+                    s_.wait_stream(caller)
+                    with torch.cuda.stream(s_):
+                        self.window_device(mods, e_)
+                    s_.synchronize()
+        slot = self._nwin % self._nslots
+        eng, st = self._slots[slot]
+        st = st if st is not None else caller
+        self._nwin += 1
+        if self._nslots == 1 or self._pool is None:
+            if self._nslots > 1:
+                st.wait_stream(caller)
+            job = self._device_side(mods, n_clusters, trigger, t_start, eng, st, None)
+            if self._pool is None:
+                self._chain(self._cluster(job), job)
+            else:
+                self._pending.append(self._pool.submit(self._chain, self._kpool.submit(self._cluster, job), job))
+            return
+        while len(self._pending) >= self._max_inflight + self._nslots:  # back-pressure (pinned buffers, engines)
+            self._pending.popleft().result()
+        wait_ev = torch.cuda.Event()
+        wait_ev.record(caller)
+        fut_job = self._dpools[slot].submit(self._device_side, mods, n_clusters, trigger, t_start, eng, st, wait_ev)
+        fut_cluster = self._kpool.submit(self._cluster_after, fut_job)
+        self._pending.append(self._pool.submit(self._chain_after, fut_cluster, fut_job))
 
     def flush(self):
         while self._pending:
@@ -290,6 +331,9 @@ class StreamPipeline:
         for s in (self.swfd, self.fswfd):
             if s is not None:
                 s.close()
+        for dp in (self._dpools or []):
+            dp.shutdown()
+        self._dpools = None
         for e, _ in (self._slots or [])[1:]:
             e.close()
         self._slots = None
