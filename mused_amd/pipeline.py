@@ -159,7 +159,9 @@ class StreamPipeline:
         metric = mo._metric_for(t)
         if not self.assume_finite and m.is_floating_point():
             if self._chk is None:
-                self._chk = torch.cuda.Stream()
+                with self._pin_lock:  # slot threads may get here together
+                    if self._chk is None:
+                        self._chk = torch.cuda.Stream()
             # the rows of a window are resident before the window is processed (run() uploads the stream first;
             # process_window's callers hand over resident tensors): the check does not wait for the main stream
             with torch.cuda.stream(self._chk):
