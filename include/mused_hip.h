@@ -91,6 +91,14 @@ int mused_record_scores(const double* rec, int n, int kind, double* S, void* str
 int mused_jaccard_scores(const int* rowptr, const int* tags, const int* postptr, const int* postrow, int n, int n_tags,
                          double* S, void* stream);
 int mused_group_mask(const int* ids, int n, unsigned long long* out_mask, int mask_words, void* stream);
+/* The same selections as mused_record_scores / mused_jaccard_scores followed by mused_select_k_smallest, WITHOUT the
+ * n x n score matrix: the scores of a row are computed into LDS by the selection kernel itself (n <= 16384 records,
+ * n <= 15000 tag sets).  Outputs as
+ * mused_select_k_smallest (out_idx and out_mask may each be NULL; ties to the smaller row; own column cleared). */
+int mused_record_knn(const double* rec, int n, int kind, int k, int* out_idx, unsigned long long* out_mask, int mask_words,
+                     void* stream);
+int mused_jaccard_knn(const int* rowptr, const int* tags, const int* postptr, const int* postrow, int n, int n_tags, int k,
+                      int* out_idx, unsigned long long* out_mask, int mask_words, void* stream);
 
 /* ---- a3 / a4: adjacency bitmasks -------------------------------------------------------------
  * An adjacency is n rows x words uint64 (words >= ceil(n/64)); bit j of row i <=> A[i][j] = 1. */

@@ -36,6 +36,8 @@ _PROTOS = {
     "mused_knn_fused": (_i, [_vp, _i, _l, _i, _l, _i, _i, _vp, _l, _i, _vp, _vp, _i, _vp, _vp]),
     "mused_record_scores": (_i, [_vp, _i, _i, _vp, _vp]),
     "mused_group_mask": (_i, [_vp, _i, _vp, _i, _vp]),
+    "mused_record_knn": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mused_jaccard_knn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mused_jaccard_scores": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mused_adj_fuse": (_i, [C.POINTER(_vp), _i, _i, _i, _vp, _vp]),
     "mused_adj_degrees": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),

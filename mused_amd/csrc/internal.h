@@ -6,6 +6,13 @@
 
 namespace mused {
 
+// knn.hip: per-row selection of the k smallest scores computed on the fly (no n x n score matrix), see select_k_kernel
+int select_from_records(const double* rec, int n, int kind, int k, int* out_idx, unsigned long long* out_mask,
+                        int mask_words, hipStream_t stream);
+int select_from_tag_sets(const int* rowptr, const int* tags, const int* postptr, const int* postrow, int n, int k,
+                         int* out_idx, unsigned long long* out_mask, int mask_words, hipStream_t stream);
+int select_max_fused_rows(bool tag_sets);
+
 // hipGraph stream captures of this library are serialised across host threads (see pipeline.py: window slots)
 std::mutex& capture_mutex();
 

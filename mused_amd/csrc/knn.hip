@@ -9,6 +9,7 @@
 //   the smaller index (sklearn's heap keeps the earlier candidate on ties).
 #include "gemm_f64.h"
 #include "internal.h"
+#include "meta_scores.h"
 
 namespace mused {
 
@@ -119,6 +120,7 @@ static int scores_launch(const T* X, long n, int d, long ld, int metric, double*
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_WAVES = SEL_THREADS / 64;
 constexpr int SEL_MAX_LDS_KEYS = 16384;  // 128 KiB of keys cached in LDS; longer rows re-read global
+constexpr int SEL_MAX_JACCARD_ROWS = 15000;  // keys + 16-bit intersection counters of one row: 150 KB of the 160 KB
 
 __device__ __forceinline__ int block_excl_scan(int v, int* ws /*[SEL_WAVES]*/, int& total) {
   // exclusive prefix sum over the workgroup; ws in LDS
@@ -143,9 +145,23 @@ __device__ __forceinline__ int block_excl_scan(int v, int* ws /*[SEL_WAVES]*/, i
   return base + x - v;
 }
 
+// Where a row of scores comes from.  SRC_MATRIX: row `row` of S (the classic path).  The others compute the row on the
+// fly (rows of at most SEL_MAX_LDS_KEYS scores, kept as keys in LDS) -- the metadata modality types of meta.hip without
+// an n x n score matrix: SRC_HAVERSINE / SRC_TIME from n x 2 records, SRC_JACCARD from tag sets (CSR + posting lists).
+enum { SRC_MATRIX = 0, SRC_HAVERSINE = 1, SRC_TIME = 2, SRC_JACCARD = 3 };
+struct SelSource {
+  const double* rec;     // SRC_HAVERSINE / SRC_TIME: n x 2 records
+  const int* rowptr;     // SRC_JACCARD: tag sets as CSR ...
+  const int* tags;
+  const int* postptr;    // ... and the posting lists of the tags
+  const int* postrow;
+};
+
+template <int SRC>
 __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __restrict__ S, long ld, int n, int k,
                                                              int* __restrict__ out_idx /* n x k or null */,
-                                                             unsigned long long* __restrict__ out_mask, int mask_words) {
+                                                             unsigned long long* __restrict__ out_mask, int mask_words,
+                                                             SelSource src) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sel_smem[];
   __shared__ int hist[256];
   __shared__ int ws[SEL_WAVES];
@@ -157,14 +173,49 @@ __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __r
 
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
-  const double* srow = S + (long)row * ld;
-  const bool cached = (n <= SEL_MAX_LDS_KEYS);
+  const double* srow = SRC == SRC_MATRIX ? S + (long)row * ld : nullptr;
+  const bool cached = (SRC != SRC_MATRIX) || (n <= SEL_MAX_LDS_KEYS);
   unsigned long long* keys = sel_smem;  // [n] when cached
+
+  [[maybe_unused]] unsigned short* inter = reinterpret_cast<unsigned short*>(sel_smem + n);  // SRC_JACCARD: behind the keys
+  [[maybe_unused]] double r0 = 0.0, r1 = 0.0;
+  [[maybe_unused]] int li = 0;
+  if constexpr (SRC == SRC_HAVERSINE || SRC == SRC_TIME) {
+    r0 = src.rec[2 * (long)row];
+    r1 = src.rec[2 * (long)row + 1];
+  }
+  if constexpr (SRC == SRC_JACCARD) {
+    // intersection sizes of this row's tag set with every row's: walk the posting lists of its tags (rows inside a
+    // list are distinct: no atomics, a barrier between lists) -- jaccard_scores_kernel of meta.hip
+    for (int j = tid; j < n; j += SEL_THREADS) inter[j] = 0;
+    __syncthreads();
+    const int t0 = src.rowptr[row], t1 = src.rowptr[row + 1];
+    li = t1 - t0;
+    for (int t = t0; t < t1; ++t) {
+      const int tag = src.tags[t];
+      const int p1 = src.postptr[tag + 1];
+      for (int q = src.postptr[tag] + tid; q < p1; q += SEL_THREADS) inter[src.postrow[q]] += 1;
+      __syncthreads();
+    }
+  }
+  auto score_at = [&](int i) -> double {
+    if constexpr (SRC == SRC_MATRIX) return srow[i];
+    if constexpr (SRC == SRC_HAVERSINE) return haversine_km(r0, r1, src.rec[2 * (long)i], src.rec[2 * (long)i + 1]);
+    if constexpr (SRC == SRC_TIME) return time_l1(r0, r1, src.rec[2 * (long)i], src.rec[2 * (long)i + 1]);
+    if constexpr (SRC == SRC_JACCARD) {
+      if (i == row) return 1.0;
+      const int lj = src.rowptr[i + 1] - src.rowptr[i];
+      if (li == 0 || lj == 0) return 0.0;
+      const int in = inter[i];
+      return 0.0 - (double)in / (double)(li + lj - in);
+    }
+    return 0.0;
+  };
 
   // pass 0: keys, min, max
   unsigned long long kmin = ~0ull, kmax = 0ull;
   for (int i = tid; i < n; i += SEL_THREADS) {
-    const unsigned long long key = f64_key(srow[i]);
+    const unsigned long long key = f64_key(score_at(i));
     if (cached) keys[i] = key;
     kmin = key < kmin ? key : kmin;
     kmax = key > kmax ? key : kmax;
@@ -327,21 +378,45 @@ __global__ __launch_bounds__(SEL_THREADS) void select_k_kernel(const double* __r
   }
 }
 
-static int select_launch(const double* S, long ld, int n, int k, int* out_idx, unsigned long long* out_mask,
-                         int mask_words, hipStream_t stream) {
-  const size_t lds = (n <= SEL_MAX_LDS_KEYS) ? (size_t)n * 8 : 0;
+template <int SRC>
+static int select_launch_src(const double* S, long ld, int n, int k, int* out_idx, unsigned long long* out_mask,
+                             int mask_words, const SelSource& src, hipStream_t stream) {
+  // keys of the row (cached case) + the 16-bit intersection counters of SRC_JACCARD behind them
+  const size_t lds = ((SRC != SRC_MATRIX || n <= SEL_MAX_LDS_KEYS) ? (size_t)n * 8 : 0) + (SRC == SRC_JACCARD ? (size_t)n * 2 + 8 : 0);
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(select_k_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_MAX_LDS_KEYS * 8);
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(select_k_kernel<SRC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SRC == SRC_JACCARD ? SEL_MAX_JACCARD_ROWS * 10 + 64 : SEL_MAX_LDS_KEYS * 8);
   });
   MUSED_CHECK_HIP(attr_rc);
-  hipLaunchKernelGGL(select_k_kernel, dim3(n), dim3(SEL_THREADS), lds, stream, S, ld, n, k, out_idx, out_mask,
-                     mask_words);
+  hipLaunchKernelGGL(select_k_kernel<SRC>, dim3(n), dim3(SEL_THREADS), lds, stream, S, ld, n, k, out_idx, out_mask,
+                     mask_words, src);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }
+
+static int select_launch(const double* S, long ld, int n, int k, int* out_idx, unsigned long long* out_mask,
+                         int mask_words, hipStream_t stream) {
+  return select_launch_src<SRC_MATRIX>(S, ld, n, k, out_idx, out_mask, mask_words, SelSource{}, stream);
+}
+
+// selection straight from the records / tag sets (rows of at most SEL_MAX_LDS_KEYS scores): meta.hip's C entry points
+int select_from_records(const double* rec, int n, int kind, int k, int* out_idx, unsigned long long* out_mask,
+                        int mask_words, hipStream_t stream) {
+  SelSource src{};
+  src.rec = rec;
+  if (kind == 0) return select_launch_src<SRC_HAVERSINE>(nullptr, 0, n, k, out_idx, out_mask, mask_words, src, stream);
+  return select_launch_src<SRC_TIME>(nullptr, 0, n, k, out_idx, out_mask, mask_words, src, stream);
+}
+int select_from_tag_sets(const int* rowptr, const int* tags, const int* postptr, const int* postrow, int n, int k,
+                         int* out_idx, unsigned long long* out_mask, int mask_words, hipStream_t stream) {
+  SelSource src{};
+  src.rowptr = rowptr; src.tags = tags; src.postptr = postptr; src.postrow = postrow;
+  return select_launch_src<SRC_JACCARD>(nullptr, 0, n, k, out_idx, out_mask, mask_words, src, stream);
+}
+int select_max_fused_rows(bool tag_sets) { return tag_sets ? SEL_MAX_JACCARD_ROWS : SEL_MAX_LDS_KEYS; }
 
 }  // namespace mused
 

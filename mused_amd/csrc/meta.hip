@@ -8,25 +8,14 @@
 
 #include "common.h"
 #include "internal.h"
+#include "meta_scores.h"
 
 // no fused multiply-add anywhere in this file: the scores follow the host expressions operation by operation
 #pragma clang fp contract(off)
 
 namespace mused {
 
-// ---- two-column records ------------------------------------------------------------------------------------------
-// Every operation is rounded on its own (no fused multiply-add), in the order the reference's Python expression
-// evaluates it, so that the only difference to the host arithmetic is the last-bit accuracy of sin / cos / asin.
-__device__ __forceinline__ double haversine_km(double lat1d, double lon1d, double lat2d, double lon2d) {
-  const double d2r = 3.14159265358979323846 / 180.0;  // math.radians: x * (pi / 180)
-  const double lat1 = __dmul_rn(lat1d, d2r), lon1 = __dmul_rn(lon1d, d2r);
-  const double lat2 = __dmul_rn(lat2d, d2r), lon2 = __dmul_rn(lon2d, d2r);
-  const double sdlat = sin(__dmul_rn(__dsub_rn(lat2, lat1), 0.5));
-  const double sdlon = sin(__dmul_rn(__dsub_rn(lon2, lon1), 0.5));
-  const double cc = __dmul_rn(cos(lat1), cos(lat2));
-  const double a = __dadd_rn(__dmul_rn(sdlat, sdlat), __dmul_rn(cc, __dmul_rn(sdlon, sdlon)));
-  return __dmul_rn(__dmul_rn(2.0, asin(sqrt(a))), 6371.0);
-}
+// ---- two-column records: haversine_km / time_l1 live in meta_scores.h (shared with the selection kernel of knn.hip) ---
 
 template <int KIND>
 __global__ __launch_bounds__(256) void record_scores_kernel(const double* __restrict__ rec, int n, double* __restrict__ S) {
@@ -44,7 +33,7 @@ __global__ __launch_bounds__(256) void record_scores_kernel(const double* __rest
       // the query row is location1, the candidate location2 (the formula is symmetric in them)
       s = haversine_km(a0, a1, bj0, bj1);
     } else {
-      s = __dadd_rn(fabs(__dsub_rn(bj0, a0)), fabs(__dsub_rn(bj1, a1)));
+      s = time_l1(a0, a1, bj0, bj1);
     }
     S[(long)i * n + j] = s;
   }
@@ -139,6 +128,23 @@ int mused_jaccard_scores(const int* rowptr, const int* tags, const int* postptr,
   jaccard_scores_kernel<<<n, 256, lds, (hipStream_t)stream>>>(rowptr, tags, postptr, postrow, n, S);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
+}
+
+// The same selections WITHOUT the n x n score matrix (n <= 16384: the scores of a row live in LDS only): the k closest
+// rows per row by haversine / time distance, resp. the k rows of largest Jaccard similarity; ties to the smaller row;
+// outputs as mused_select_k_smallest.
+int mused_record_knn(const double* rec, int n, int kind, int k, int* out_idx, unsigned long long* out_mask, int mask_words,
+                     void* stream) {
+  MUSED_REQUIRE(rec && n > 0 && (kind == 0 || kind == 1) && k >= 1 && k <= n && n <= select_max_fused_rows(false),
+                "mused_record_knn: bad arguments (n=%d kind=%d k=%d)", n, kind, k);
+  return select_from_records(rec, n, kind, k, out_idx, out_mask, mask_words, (hipStream_t)stream);
+}
+
+int mused_jaccard_knn(const int* rowptr, const int* tags, const int* postptr, const int* postrow, int n, int n_tags, int k,
+                      int* out_idx, unsigned long long* out_mask, int mask_words, void* stream) {
+  MUSED_REQUIRE(rowptr && postptr && n > 0 && n_tags >= 0 && k >= 1 && k <= n && n <= select_max_fused_rows(true),
+                "mused_jaccard_knn: bad arguments (n=%d k=%d)", n, k);
+  return select_from_tag_sets(rowptr, tags, postptr, postrow, n, k, out_idx, out_mask, mask_words, (hipStream_t)stream);
 }
 
 }  // extern "C"

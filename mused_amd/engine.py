@@ -25,6 +25,7 @@ from . import _lib
 from ._lib import F32, F64, I64, METRIC_COSINE, METRIC_L2, MusedError, call
 
 _DT = {torch.float32: F32, torch.float64: F64, torch.int64: I64}
+_FUSED_META_ROWS = 15000  # mused_record_knn (<= 16384) / mused_jaccard_knn (<= 15000) keep one row of scores in LDS
 
 
 def _require_gpu():
@@ -236,7 +237,14 @@ class WindowEngine:
         n = rec.shape[0]
         if n > self.n_max or rec.shape[1] != 2:
             raise ValueError(f"{kind}: need (n <= {self.n_max}) x 2 records, got {tuple(rec.shape)}")
-        call("mused_record_scores", ptr(rec), n, {"location": 0, "time": 1}[kind], ptr(self.scores), stream_ptr())
+        kcode = {"location": 0, "time": 1}[kind]
+        if n <= _FUSED_META_ROWS and self.knn_mode != "classic":
+            # scores of a row computed into LDS by the selection kernel itself: no n x n score matrix
+            w = words_for(n)
+            mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+            call("mused_record_knn", ptr(rec), n, kcode, kk, None, ptr(mask), w, stream_ptr())
+            return Adjacency(mask, n)
+        call("mused_record_scores", ptr(rec), n, kcode, ptr(self.scores), stream_ptr())
         return self._select(n, kk)
 
     def jaccard_adjacency(self, rowptr, tags, n_tags: int, kk: int) -> Adjacency:
@@ -253,6 +261,13 @@ class WindowEngine:
         postptr = np.concatenate([[0], np.cumsum(np.bincount(tags, minlength=max(n_tags, 1)))]).astype(np.int32)
         dev = [torch.from_numpy(a).to(self.device) for a in (rowptr, tags if len(tags) else np.zeros(1, np.int32),
                                                               postptr, postrow if len(postrow) else np.zeros(1, np.int32))]
+        if n <= _FUSED_META_ROWS and self.knn_mode != "classic":
+            w = words_for(n)
+            mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+            call("mused_jaccard_knn", ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), n, int(n_tags), kk, None, ptr(mask),
+                 w, stream_ptr())
+            self._keep = dev  # the CSR arrays stay alive until the stream has consumed them (next call replaces them)
+            return Adjacency(mask, n)
         call("mused_jaccard_scores", ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), n, int(n_tags), ptr(self.scores),
              stream_ptr())
         return self._select(n, kk)

@@ -144,6 +144,26 @@ def test_metadata_degenerate_inputs_and_window_golden():
     assert np.array_equal(km, g["win_labels"])
 
 
+def test_metadata_selection_needs_no_score_matrix():
+    """mused_record_knn / mused_jaccard_knn (scores of a row computed into LDS by the selection kernel) == the score-matrix
+    path (mused_record_scores / mused_jaccard_scores + mused_select_k_smallest), and allocate no n x n workspace."""
+    from mused_amd import matrix_operations as mo
+    from mused_amd import synth
+    from mused_amd.engine import WindowEngine
+
+    n, k = 1500, 40
+    cols, _ = synth.metadata_stream(n, 5, events=6, users=30, integer_time=True)
+    fused_eng, classic_eng = WindowEngine(n), WindowEngine(n)
+    classic_eng.knn_mode = "classic"
+    for t in ("location", "time", "tags"):
+        a = mo.adjacency_on_device(cols[t], t, k, engine=fused_eng)
+        b = mo.adjacency_on_device(cols[t], t, k, engine=classic_eng)
+        assert torch.equal(a.mask, b.mask), t
+    assert fused_eng._scores is None and classic_eng._scores is not None
+    fused_eng.close()
+    classic_eng.close()
+
+
 def test_metadata_scores_at_window_size():
     """n = 2,500 rows (a quarter window; the oracle's haversine is a Python double loop): device adjacency == oracle for
     every metadata type, and the same-user relation has no degree bound (its CSR is sized from the real edge count)."""
