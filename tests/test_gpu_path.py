@@ -164,6 +164,41 @@ def test_metadata_selection_needs_no_score_matrix():
     classic_eng.close()
 
 
+def test_metadata_c_abi_index_outputs():
+    """mused_record_knn / mused_jaccard_knn with BOTH outputs (neighbour indices and bitmask) against
+    mused_record_scores / mused_jaccard_scores + mused_select_k_smallest, straight through the C ABI."""
+    from mused_amd import _lib, synth
+    from mused_amd.engine import ptr, stream_ptr, words_for
+
+    n, k = 700, 23
+    cols, _ = synth.metadata_stream(n, 9, missing=0.0, integer_time=True)
+    w = words_for(n)
+    S = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    for kind, name in ((0, "location"), (1, "time")):
+        rec = torch.from_numpy(np.ascontiguousarray(cols[name], dtype=np.float64)).cuda()
+        i1 = torch.empty((n, k), dtype=torch.int32, device="cuda"); m1 = torch.empty((n, w), dtype=torch.int64, device="cuda")
+        i2 = torch.empty_like(i1); m2 = torch.empty_like(m1)
+        _lib.call("mused_record_knn", ptr(rec), n, kind, k, ptr(i1), ptr(m1), w, stream_ptr())
+        _lib.call("mused_record_scores", ptr(rec), n, kind, ptr(S), stream_ptr())
+        _lib.call("mused_select_k_smallest", ptr(S), n, n, k, ptr(i2), ptr(m2), w, stream_ptr())
+        assert torch.equal(i1, i2) and torch.equal(m1, m2), name
+    vocab, rowptr, ids = {}, [0], []
+    for tags in cols["tags"][:, 0]:
+        ids.extend(sorted(vocab.setdefault(t, len(vocab)) for t in set(tags)))
+        rowptr.append(len(ids))
+    rowptr = np.asarray(rowptr, dtype=np.int32); ids = np.asarray(ids, dtype=np.int32)
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rowptr))
+    order = np.argsort(ids, kind="stable")
+    postptr = np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=len(vocab)))]).astype(np.int32)
+    dev = [torch.from_numpy(a).cuda() for a in (rowptr, ids, postptr, rows[order])]
+    i1 = torch.empty((n, k), dtype=torch.int32, device="cuda"); m1 = torch.empty((n, w), dtype=torch.int64, device="cuda")
+    i2 = torch.empty_like(i1); m2 = torch.empty_like(m1)
+    _lib.call("mused_jaccard_knn", *(ptr(t) for t in dev), n, len(vocab), k, ptr(i1), ptr(m1), w, stream_ptr())
+    _lib.call("mused_jaccard_scores", *(ptr(t) for t in dev), n, len(vocab), ptr(S), stream_ptr())
+    _lib.call("mused_select_k_smallest", ptr(S), n, n, k, ptr(i2), ptr(m2), w, stream_ptr())
+    assert torch.equal(i1, i2) and torch.equal(m1, m2)
+
+
 def test_metadata_scores_at_window_size():
     """n = 2,500 rows (a quarter window; the oracle's haversine is a Python double loop): device adjacency == oracle for
     every metadata type, and the same-user relation has no degree bound (its CSR is sized from the real edge count)."""
