@@ -37,7 +37,9 @@ int gemm_splitk_reduce(const double* partial, int nsplit, long count, double* ou
 // r + ceil(n/16); with 4 (r + n) the blocked path runs (n <= 10240)
 int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, long ws_f64_len, hipStream_t st);
 // Q (n x r) <- economic Householder Q of Y (destroyed); tau: r doubles, wpart: ceil(n/512)*r + 2 n doubles
-int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart, hipStream_t st);
+// run_if (optional, device int): the whole chain is a no-op unless *run_if != 0 (fallback of the Cholesky-QR path)
+int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart, hipStream_t st,
+                const int* run_if = nullptr);
 // Y = A Q for binary CSR A
 int spmm_binary(const int* rowptr, const int* colidx, int n, const double* Q, long ldq, int r, double* Y, long ldy,
                 hipStream_t stream);

@@ -419,8 +419,12 @@ int lu_permute_l(double* Y, int n, int r, long ld, int* pivstep, double* prow, l
 // x == 0.  The one-workgroup kernel never walks the strided column of the row-major panel: the update of
 // column j - 1 (rows in parallel) exports column j to the contiguous buffer `col`, this kernel turns it into
 // the contiguous Householder vector `vcol`, and the update of column j writes v back into Y.
+// run_if (optional, device): every kernel of the Householder chain returns at once unless *run_if != 0 -- the chain is
+// recorded into the eigenstep graph as the FALLBACK of the Cholesky-QR factorisation (rsvd.hip)
 __global__ __launch_bounds__(1024) void qr_house_kernel(const double* __restrict__ col, int n, int j,
-                                                       double* __restrict__ tau, double* __restrict__ vcol) {
+                                                       double* __restrict__ tau, double* __restrict__ vcol,
+                                                       const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   __shared__ double s_sum[16];
   __shared__ double s_scale;
   double s = 0.0;
@@ -451,7 +455,9 @@ __global__ __launch_bounds__(1024) void qr_house_kernel(const double* __restrict
 }
 
 // col[i] = Y[i][j]  (rows in parallel; only for the first column, later ones come out of qr_update_kernel)
-__global__ void qr_export_col_kernel(const double* __restrict__ Y, int n, long ld, int j, double* __restrict__ col) {
+__global__ void qr_export_col_kernel(const double* __restrict__ Y, int n, long ld, int j, double* __restrict__ col,
+                                     const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) col[i] = Y[(long)i * ld + j];
 }
@@ -461,7 +467,8 @@ __global__ void qr_export_col_kernel(const double* __restrict__ Y, int n, long l
 __global__ __launch_bounds__(1024) void qr_dot_kernel(const double* __restrict__ Y, long ldy, int j,
                                                      const double* __restrict__ vcol, const double* __restrict__ T,
                                                      long ldt, int n, int c_lo, int c_hi, double* __restrict__ wpart,
-                                                     int wld) {
+                                                     int wld, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   __shared__ double red[16][64];
   const int chunk = blockIdx.x;
   const int r0 = max(j, chunk * PANEL_ROWS_PER_WG);
@@ -490,7 +497,9 @@ __global__ __launch_bounds__(256) void qr_update_kernel(double* __restrict__ Y, 
                                                        const double* __restrict__ vcol, double* __restrict__ col,
                                                        double* __restrict__ T, long ldt, int n, int c_lo, int c_hi,
                                                        const double* __restrict__ wpart, int wld, int nchunk,
-                                                       int first_chunk, const double* __restrict__ tau) {
+                                                       int first_chunk, const double* __restrict__ tau,
+                                                       const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   extern __shared__ double w[];  // [c_hi - c_lo]
   const double tj = tau[j];
   if (tj == 0.0 && !vcol) return;
@@ -516,7 +525,8 @@ __global__ __launch_bounds__(256) void qr_update_kernel(double* __restrict__ Y, 
   }
 }
 
-__global__ void set_identity_kernel(double* __restrict__ Q, int n, int r, long ld) {
+__global__ void set_identity_kernel(double* __restrict__ Q, int n, int r, long ld, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * r) return;
   const int row = (int)(gid / r), c = (int)(gid - (long)row * r);
@@ -524,29 +534,30 @@ __global__ void set_identity_kernel(double* __restrict__ Q, int n, int r, long l
 }
 
 int qr_economic(double* Y, int n, int r, long ldy, double* Q, long ldq, double* tau, double* wpart,
-                hipStream_t st) {
+                hipStream_t st, const int* run_if) {
   // requires n >= r.  wpart: ceil(n/512) * r partial sums, then col[n], then vcol[n]
   const int nchunk = cdiv(n, PANEL_ROWS_PER_WG);
   const int wld = r;
   double* col = wpart + (long)nchunk * r;
   double* vcol = col + n;
-  hipLaunchKernelGGL(qr_export_col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, Y, n, ldy, 0, col);
+  hipLaunchKernelGGL(qr_export_col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, Y, n, ldy, 0, col, run_if);
   for (int j = 0; j < r; ++j) {
-    hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, col, n, j, tau, vcol);
+    hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, col, n, j, tau, vcol, run_if);
     const int first = j / PANEL_ROWS_PER_WG;
     if (j + 1 < r)
-      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, vcol, Y, ldy, n, j + 1, r, wpart, wld);
+      hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, vcol, Y, ldy, n, j + 1, r, wpart, wld,
+                         run_if);
     // (the last column has nothing to update: c_lo = c_hi = r; the launch only writes v back into Y)
     hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j), st, Y, ldy, j, vcol,
-                       col, Y, ldy, n, j + 1, r, wpart, wld, nchunk, first, tau);
+                       col, Y, ldy, n, j + 1, r, wpart, wld, nchunk, first, tau, run_if);
   }
-  hipLaunchKernelGGL(set_identity_kernel, dim3(cdiv((long)n * r, 256)), dim3(256), 0, st, Q, n, r, ldq);
+  hipLaunchKernelGGL(set_identity_kernel, dim3(cdiv((long)n * r, 256)), dim3(256), 0, st, Q, n, r, ldq, run_if);
   for (int j = r - 1; j >= 0; --j) {
     const int first = j / PANEL_ROWS_PER_WG;
     hipLaunchKernelGGL(qr_dot_kernel, dim3(nchunk), dim3(1024), 0, st, Y, ldy, j, (const double*)nullptr, Q, ldq, n, j,
-                       r, wpart, wld);
+                       r, wpart, wld, run_if);
     hipLaunchKernelGGL(qr_update_kernel, dim3(cdiv(n - j, 16)), dim3(256), sizeof(double) * (r - j), st, Y, ldy, j,
-                       (const double*)nullptr, (double*)nullptr, Q, ldq, n, j, r, wpart, wld, nchunk, first, tau);
+                       (const double*)nullptr, (double*)nullptr, Q, ldq, n, j, r, wpart, wld, nchunk, first, tau, run_if);
   }
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;

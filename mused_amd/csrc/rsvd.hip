@@ -36,6 +36,7 @@ struct Rsvd {
 };
 
 constexpr int GRAM_KCHUNK = 512;
+constexpr int CHOLQR_KCHUNK = 128;  // split-K chunk of the normaliser's Gram: ~4 x more workgroups than the final Gram
 
 __global__ void gram_reduce_pad_kernel(const double* __restrict__ partial, int nsplit, int rc, double* __restrict__ G,
                                        int en) {
@@ -48,6 +49,125 @@ __global__ void gram_reduce_pad_kernel(const double* __restrict__ partial, int n
     const int a = i < j ? i : j, b = i < j ? j : i;
     for (int z = 0; z < nsplit; ++z) s += partial[(long)z * rc * rc + (long)a * rc + b];
   }
+  G[gid] = s;
+}
+
+// ---- Cholesky-QR normaliser of the power iterations -----------------------------------------------------------------
+// sklearn normalises the iterates Y of its randomized range finder with an LU factorisation (extmath.py:343-351,
+// power_iteration_normalizer = "LU" for n_iter = 5): any well-conditioned basis of span(Y) serves -- the range after the
+// last iteration is the same subspace, so singular values, embedding and labels agree with the LU chain to rounding
+// (measured on every golden: sigma to 1e-15, embedding to 1e-12, k-means labels identical) -- and a partially pivoted LU
+// of a 10,000 x 138 panel is ~70 dependent launches.  Here:  G = Y^T Y (split-K MFMA GEMM, fixed-order reduction),
+// G + delta I = L L^T in LDS (one workgroup),  Q = Y L^-T by forward substitution, 64 rows per workgroup: 4 launches.  delta = 16 r eps max(diag G)
+// keeps the factorisation defined when Y is rank deficient (adjacency matrices of rank < r: same-user cliques, tiny
+// windows); the directions it then leaves unnormalised are noise that the final Householder QR orthogonalises, exactly
+// as the garbage columns of a rank-deficient LU are.  MUSED_RSVD_NORMALIZER=lu restores the LU chain.
+constexpr int CHOLQR_MAX_R = 143;  // packed lower triangle of L (r (r + 1) / 2 doubles) + 64 rows of Y in LDS: 157 KB
+
+__device__ __forceinline__ int tri_at(int i, int k) { return i * (i + 1) / 2 + k; }
+
+// one workgroup: G (r x r, full) -> packed L = chol(G + delta I), written to Lg (r (r + 1) / 2 doubles).  The trailing
+// update of a step is dealt to a 16 x 16 grid of threads (rows i = j + 1 + ti (mod 16), columns k = j + 1 + tk (mod 16)).
+__global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ G, int r, double* __restrict__ Lg,
+                                                   int* __restrict__ weak_flag) {
+  extern __shared__ double cq_smem[];
+  __shared__ double s_red[4];
+  __shared__ double s_delta;
+  const int t = threadIdx.x, ti = t >> 4, tk = t & 15;
+  const int ntri = r * (r + 1) / 2;
+  double* Lp = cq_smem;
+  double dmax = 0.0;
+  for (int e = t; e < r * r; e += 256) {
+    const int i = e / r, k = e - i * r;
+    if (k <= i) {
+      const double v = G[e];
+      Lp[tri_at(i, k)] = v;
+      if (k == i) dmax = fmax(dmax, v);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+  if ((t & 63) == 0) s_red[t >> 6] = dmax;
+  __syncthreads();
+  if (t == 0) s_delta = 16.0 * r * 2.220446049250313e-16 * fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  __syncthreads();
+  const double delta = s_delta;
+  for (int j = 0; j < r; ++j) {
+    const double piv0 = Lp[tri_at(j, j)];
+    // a pivot below 1e-11 of the largest diagonal entry: Y is (numerically) rank deficient or worse conditioned than 3e5 --
+    // fine for a normaliser, not for the final orthonormal basis (the caller then runs the Householder chain)
+    if (weak_flag && t == 0 && !(piv0 > 1e-11 * (delta / (16.0 * r * 2.220446049250313e-16)))) *weak_flag = 1;
+    const double piv = piv0 + delta;  // the same (final) value for every thread
+    const double d = sqrt(piv > delta ? piv : delta);
+    const double inv = 1.0 / d;
+    __syncthreads();  // all have read the pivot
+    if (t == 0) Lp[tri_at(j, j)] = d;
+    for (int i = j + 1 + t; i < r; i += 256) Lp[tri_at(i, j)] *= inv;
+    __syncthreads();
+    for (int i = j + 1 + ti; i < r; i += 16) {  // L[i][k] -= L[i][j] L[k][j], j < k <= i
+      const double lij = Lp[tri_at(i, j)];
+      double* row = Lp + tri_at(i, 0);
+      int k = j + 1 + tk;
+      for (; k + 48 <= i; k += 64) {  // four entries per pass: their LDS reads are in flight together
+        const double a0 = row[k], a1 = row[k + 16], a2 = row[k + 32], a3 = row[k + 48];
+        const double b0 = Lp[tri_at(k, j)], b1 = Lp[tri_at(k + 16, j)], b2 = Lp[tri_at(k + 32, j)], b3 = Lp[tri_at(k + 48, j)];
+        row[k] = a0 - lij * b0; row[k + 16] = a1 - lij * b1; row[k + 32] = a2 - lij * b2; row[k + 48] = a3 - lij * b3;
+      }
+      for (; k <= i; k += 16) row[k] -= lij * Lp[tri_at(k, j)];
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < ntri; e += 256) Lg[e] = Lp[e];
+}
+
+// Q = Y L^-T, 64 rows of Y per workgroup: row y solves L q^T = y^T by forward substitution.  Four lanes share a row (the
+// inner sum over m < k is dealt to them, two DPP adds combine it); L (packed) and the 64 rows live in LDS.
+__global__ __launch_bounds__(256) void trsm_rows_kernel(const double* __restrict__ Y, long ldy, int n, int r,
+                                                        const double* __restrict__ Lg, double* __restrict__ Q, long ldq) {
+  extern __shared__ double cq_smem[];
+  const int t = threadIdx.x;
+  const int ntri = r * (r + 1) / 2;
+  double* Lp = cq_smem;
+  double* rows = cq_smem + ntri;  // [64][rs]: the workgroup's 64 rows, odd pitch (bank spread between the quads)
+  const int rs = r | 1;
+  for (int e = t; e < ntri; e += 256) Lp[e] = Lg[e];
+  const long row0 = (long)blockIdx.x * 64;
+  for (int e = t; e < 64 * r; e += 256) {
+    const int rr = e / r, k = e - rr * r;
+    rows[rr * rs + k] = (row0 + rr < n) ? Y[(row0 + rr) * ldy + k] : 0.0;
+  }
+  __syncthreads();
+  const int rr = t >> 2, part = t & 3;  // the 4 lanes of a quad work on row rr
+  double* q = rows + rr * rs;
+  for (int k = 0; k < r; ++k) {
+    const double* lrow = Lp + tri_at(k, 0);
+    double sum = 0.0, sum1 = 0.0, sum2 = 0.0, sum3 = 0.0;
+    int m = part;
+    for (; m + 12 < k; m += 16) {  // four independent partial sums: the LDS reads of a pass are in flight together
+      const double l0 = lrow[m], l1 = lrow[m + 4], l2 = lrow[m + 8], l3 = lrow[m + 12];
+      const double q0 = q[m], q1 = q[m + 4], q2 = q[m + 8], q3 = q[m + 12];
+      sum = fma(l0, q0, sum); sum1 = fma(l1, q1, sum1); sum2 = fma(l2, q2, sum2); sum3 = fma(l3, q3, sum3);
+    }
+    for (; m < k; m += 4) sum = fma(lrow[m], q[m], sum);
+    sum = (sum + sum1) + (sum2 + sum3);
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (part == 0) q[k] = (q[k] - sum) / lrow[k];
+    // the quad reads entry k in later steps: same wave, LDS operations of a wave complete in order
+  }
+  __syncthreads();
+  for (int e = t; e < 64 * r; e += 256) {
+    const int r2 = e / r, k = e - r2 * r;
+    if (row0 + r2 < n) Q[(row0 + r2) * ldq + k] = rows[r2 * rs + k];
+  }
+}
+
+__global__ void gram_reduce_kernel(const double* __restrict__ partial, int nsplit, int rc, double* __restrict__ G) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rc * rc) return;
+  const int i = gid / rc, j = gid - i * rc;
+  const int a = i < j ? i : j, b = i < j ? j : i;  // symmetric by construction: both triangles read the same partials
+  double s = 0.0;
+  for (int z = 0; z < nsplit; ++z) s += partial[(long)z * rc * rc + (long)a * rc + b];
   G[gid] = s;
 }
 
@@ -144,17 +264,62 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
 
   int rc = r;
   const double* Qcur = h->Q0;
-  for (int it = 0; it < n_iter; ++it) {
-    RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
-    RC(lu_permute_l(h->Qa, n, rc, ld, h->pivstep, h->prow, h->prow_len, st));
-    rc = n < rc ? n : rc;
-    RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qa, ld, rc, h->Qb, ld, st));
-    RC(lu_permute_l(h->Qb, n, rc, ld, h->pivstep, h->prow, h->prow_len, st));
-    Qcur = h->Qb;
+  static const bool want_lu = [] {
+    const char* e = getenv("MUSED_RSVD_NORMALIZER");
+    return e && (e[0] == 'l' || e[0] == 'L');
+  }();
+  const bool cholqr = !want_lu && r <= CHOLQR_MAX_R && r <= n;
+  if (cholqr) {
+    const int nsp = cdiv(n, CHOLQR_KCHUNK);
+    const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
+    const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(r | 1);
+    // Y = (A | A^T) Q in Qa;  G = Y^T Y in U;  L = chol(G + delta I) packed in Cm;  Q = Y L^-T in Qb
+    auto normalise = [&]() -> int {
+      int e;
+      if ((e = gemm_f64_splitk(false, false, h->Qa, ld, h->Qa, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st))) return e;
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)r * r, 256)), dim3(256), 0, st, h->gpart, nsp, r, h->U);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, r, h->Cm, (int*)nullptr);
+      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, h->Qa, ld, n, r, h->Cm, h->Qb, ld);
+      return MUSED_OK;
+    };
+    for (int it = 0; it < n_iter; ++it) {
+      RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
+      RC(normalise());
+      RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qb, ld, rc, h->Qa, ld, st));
+      RC(normalise());
+      Qcur = h->Qb;
+    }
+  } else {
+    for (int it = 0; it < n_iter; ++it) {
+      RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
+      RC(lu_permute_l(h->Qa, n, rc, ld, h->pivstep, h->prow, h->prow_len, st));
+      rc = n < rc ? n : rc;
+      RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qa, ld, rc, h->Qb, ld, st));
+      RC(lu_permute_l(h->Qb, n, rc, ld, h->pivstep, h->prow, h->prow_len, st));
+      Qcur = h->Qb;
+    }
   }
   RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
   rc = n < rc ? n : rc;
-  RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st));
+  if (cholqr) {
+    // final orthonormal basis: Cholesky-QR twice (Qa -> Qb -> Qf); a weak pivot in either pass raises flags[2] and the
+    // Householder chain below (otherwise a string of no-op launches) recomputes Qf from the untouched Y in Qa
+    const int nsp = cdiv(n, CHOLQR_KCHUNK);
+    const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
+    const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(r | 1);
+    const double* src = h->Qa;
+    double* dsts[2] = {h->Qb, h->Qf};
+    for (int pass = 0; pass < 2; ++pass) {
+      RC(gemm_f64_splitk(false, false, src, ld, src, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st));
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)r * r, 256)), dim3(256), 0, st, h->gpart, nsp, r, h->U);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, r, h->Cm, h->flags + 2);
+      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, src, ld, n, r, h->Cm, dsts[pass], ld);
+      src = dsts[pass];
+    }
+    RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st, h->flags + 2));
+  } else {
+    RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st));
+  }
   RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qf, ld, rc, h->Bt, ld, st));
 
   const int nsplit = cdiv(n, GRAM_KCHUNK);
@@ -213,7 +378,8 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
   h->eig_n = (r_max + 1) & ~1;
   const size_t words = (n_max + 63) / 64;
   const size_t panel = sizeof(double) * (size_t)n_max * r_max;
-  const int nsplit = cdiv(n_max, GRAM_KCHUNK);
+  // partial Grams: the final Gram's splits, or the normaliser's finer ones when it can run (r <= CHOLQR_MAX_R)
+  const int nsplit = r_max <= CHOLQR_MAX_R ? cdiv(n_max, CHOLQR_KCHUNK) : cdiv(n_max, GRAM_KCHUNK);
 #define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))
   ALLOC(h->mask, 8 * words * n_max);
   ALLOC(h->mask_t, 8 * words * n_max);
@@ -233,6 +399,18 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
   int rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig);
   if (rc) return rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
+  {
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] {
+      const int tri = (int)(sizeof(double) * CHOLQR_MAX_R * (CHOLQR_MAX_R + 1) / 2);
+      attr_rc = hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tri);
+      if (attr_rc == hipSuccess)
+        attr_rc = hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      tri + (int)(sizeof(double) * 64 * (CHOLQR_MAX_R | 1)));
+    });
+    MUSED_CHECK_HIP(attr_rc);
+  }
   const char* ng = getenv("MUSED_NO_GRAPH");
   h->use_graph = !(ng && ng[0] == '1');
   return MUSED_OK;

@@ -54,6 +54,11 @@ class StreamPipeline:
         # one (37-40 ms), 4 vary between runs (hardware-queue sharing).  Opt-in (default 1; MUSED_WINDOW_SLOTS for
         # process_streaming_data).  The sketch approaches carry state from window to window and keep one slot.
         self._nslots = max(1, int(window_slots)) if (approach != "SWFDMC" and not feature_sketch) else 1
+        # every engine records its eigenstep graph ONCE, in the caller's thread, before the slot threads exist (see
+        # process_window): a modality without an edge bound ("username") would re-create the handle -- and re-capture,
+        # beside the HIP calls of the other threads, which ROCm 7.2 does not survive -- whenever a window has more edges
+        if any(mo.edges_per_row(t, self.k) is None for t in (modality_types or [])):
+            self._nslots = 1
         self._slots = None        # [(engine, stream)], built at the first window
         self._nwin = 0
         self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)

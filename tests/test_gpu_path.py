@@ -476,6 +476,30 @@ def test_headline_shape_swfd_lanes_match_oracle_and_single_sketches():
         sk.close()
 
 
+def test_rsvd_rank_deficient_adjacency_matches_oracle(eng):
+    """Adjacency of rank < n_components + 10 (only 20 of 400 rows have neighbours): the Cholesky-QR normaliser meets zero
+    pivots, its weak-pivot flag sends the final basis through the Householder chain; singular values as the oracle's
+    (= the reference's LU / QR chain), zeros included."""
+    from mused_amd import matrix_operations as mo
+    from oracle import mo_oracle as omo
+
+    rng = np.random.default_rng(5)
+    Xs = rng.standard_normal((400, 6))
+    Xs[rng.permutation(400)[20:], 0] = np.nan  # rows without a valid neighbourhood (matrix_operations.py:114-115)
+    A = omo.create_adjacency_matrix(Xs, "", 5)
+    assert np.linalg.matrix_rank(A) <= 20 < 30
+    _, sig_o, _ = omo.randomized_svd_reduce(A, 20, 3)
+    adj = mo.adjacency_on_device(Xs, "", 5, engine=eng)
+    _, sig_d = eng.svd_reduce(adj, 20, 3)
+    np.testing.assert_allclose(sig_d.cpu().numpy(), sig_o, rtol=0, atol=1e-8 * sig_o[0])
+    # and a full-rank window right after it on the same handle (flag cleared per call)
+    X = rng.standard_normal((400, 12))
+    A2 = omo.create_adjacency_matrix(X, "", 10)
+    _, s2o, _ = omo.randomized_svd_reduce(A2, 20, 3)
+    _, s2d = eng.svd_reduce(mo.adjacency_on_device(X, "", 10, engine=eng), 20, 3)
+    np.testing.assert_allclose(s2d.cpu().numpy(), s2o, rtol=1e-9)
+
+
 def test_rsvd_edge_overflow_is_flagged_and_memory_safe(eng):
     """More edges than nnz_cap (cosine selects k + 1 per row; a zero row is not its own nearest): the neighbour lists
     are truncated inside their buffer, flags[0] is raised and the host check raises; with the right cap it is clean."""
