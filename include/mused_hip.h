@@ -133,6 +133,13 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
 /* device int[4] raised by mused_rsvd_reduce (flags[0] != 0: more than nnz_cap edges -> lists truncated, result
  * invalid but memory-safe); copy it on the same stream behind the call for a sync-free check */
 const int* mused_rsvd_flags(void* handle);
+/* How the eigenstep builds its bases.  0 (default): Cholesky-QR (Gram + Cholesky + triangular solve) with the
+ * Householder chain recorded behind a weak-pivot flag: self-contained.  1: Cholesky-QR only -- flags[2] != 0 (third int of
+ * mused_rsvd_flags) after a call means the result is INVALID (numerically rank-deficient panel): repeat the call on a
+ * handle in mode 2.  2: the reference's chain (LU-normalised power iterations, Householder QR), launched kernel by kernel
+ * without graph capture. */
+int mused_rsvd_set_mode(void* handle, int mode);
+
 /* BLOCKING: flags_out[0] != 0 -> more than nnz_cap edges; stats_out = {max out-deg, nnz, max in-deg, nnz} (HOST) */
 int mused_rsvd_status(void* handle, int* flags_out, int* stats_out, void* stream);
 

@@ -46,6 +46,7 @@ _PROTOS = {
     "mused_adj_to_dense": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mused_adj_from_dense": (_i, [_vp, _i, _i, _l, _i, _vp, _vp, _vp]),
     "mused_rsvd_create": (_i, [_i, _i, _l, _i, C.POINTER(_vp)]),
+    "mused_rsvd_set_mode": (_i, [_vp, _i]),
     "mused_rsvd_destroy": (_i, [_vp]),
     "mused_rsvd_mask_buffer": (_vp, [_vp]),
     "mused_rsvd_set_q0": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -31,6 +31,8 @@ struct Rsvd {
   hipGraph_t graph;
   hipGraphExec_t exec;
   bool have_graph, use_graph;
+  int mode;  // mused_rsvd_set_mode: 0 Cholesky-QR + Householder fallback recorded in the graph, 1 Cholesky-QR only (the caller
+             // reads flags[2]), 2 the reference's LU / Householder chain, launched kernel by kernel
   int g_n, g_r, g_ncomp, g_iter;
   int q0_n, q0_r;
 };
@@ -268,7 +270,7 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
     const char* e = getenv("MUSED_RSVD_NORMALIZER");
     return e && (e[0] == 'l' || e[0] == 'L');
   }();
-  const bool cholqr = !want_lu && r <= CHOLQR_MAX_R && r <= n;
+  const bool cholqr = !want_lu && h->mode != 2 && r <= CHOLQR_MAX_R && r <= n;
   if (cholqr) {
     const int nsp = cdiv(n, CHOLQR_KCHUNK);
     const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
@@ -316,7 +318,7 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
       hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, src, ld, n, r, h->Cm, dsts[pass], ld);
       src = dsts[pass];
     }
-    RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st, h->flags + 2));
+    if (h->mode == 0) RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st, h->flags + 2));
   } else {
     RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st));
   }
@@ -459,7 +461,7 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
                 h->q0_r, n, r);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (h->use_graph) {
+  if (h->use_graph && h->mode != 2) {
     if (!h->have_graph || h->g_n != n || h->g_r != r || h->g_ncomp != n_comp || h->g_iter != n_iter) {
       rsvd_drop_graph(h);
       // the capture stream lives only while it records: every live HIP stream competes for the hardware queues
@@ -487,6 +489,19 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
   if (out_components)
     MUSED_CHECK_HIP(hipMemcpyAsync(out_components, h->Vsel, sizeof(double) * (size_t)n * n_comp,
                                    hipMemcpyDeviceToDevice, st));
+  return MUSED_OK;
+}
+
+// How the eigenstep orthogonalises (see "Cholesky-QR normaliser" above).  0 (default): Cholesky-QR, the Householder chain
+// recorded behind the weak-pivot flag -- self-contained, ~690 no-op launches per call when the flag stays down.
+// 1: Cholesky-QR only: flags[2] != 0 after a call means its result is INVALID (rank-deficient panel) and the call has to
+// be repeated on a handle in mode 2.  2: the reference's LU normaliser + Householder QR, launched kernel by kernel (no
+// graph capture: safe to create and use beside other host threads).
+int mused_rsvd_set_mode(void* handle, int mode) {
+  Rsvd* h = (Rsvd*)handle;
+  MUSED_REQUIRE(h && mode >= 0 && mode <= 2, "mused_rsvd_set_mode: bad arguments");
+  if (h->mode != mode) rsvd_drop_graph(h);
+  h->mode = mode;
   return MUSED_OK;
 }
 

@@ -143,6 +143,12 @@ class WindowEngine:
         self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
         self.knn_fallbacks = 0  # windows redone on the classic path because a candidate list overflowed
         self._rsvd = None
+        self._rsvd_fb = None       # fallback handle (mode 2), created on first use
+        self._rsvd_fb_key = None
+        self.rsvd_fallbacks = 0    # windows repeated on the LU / Householder chain after a weak Cholesky pivot
+        # MUSED_RSVD_MODE: "cholqr" (default: Cholesky-QR, host-side fallback), "graph" (Cholesky-QR with the Householder
+        # fallback recorded in the graph), "lu" (the reference's chain)
+        self.rsvd_mode = os.environ.get("MUSED_RSVD_MODE", "cholqr")
         self._rsvd_key = None
         self._rsvd_cap = 0
         self._q0_key = None
@@ -306,9 +312,23 @@ class WindowEngine:
             h = C.c_void_p()
             n_alloc = max(n, self.n_max)
             call("mused_rsvd_create", n_alloc, r, nnz_cap, 0, C.byref(h))
+            # Cholesky-QR without the recorded Householder fallback (~690 no-op launches per call): svd_reduce reads the
+            # weak-pivot flag and repeats the rare rank-deficient window on a handle that runs the reference's chain
+            call("mused_rsvd_set_mode", h, 1 if self.rsvd_mode == "cholqr" else 2 if self.rsvd_mode == "lu" else 0)
             self._rsvd, self._rsvd_key, self._rsvd_cap = h, (n_alloc, r), nnz_cap
             self._q0_key = None
         return self._rsvd
+
+    def _rsvd_fallback_handle(self, n: int, r: int, nnz_cap: int):
+        """Handle in mode 2 (LU normaliser + Householder QR, no graph capture) for windows the Cholesky-QR path flags."""
+        if self._rsvd_fb is None or self._rsvd_fb_key[0] < n or self._rsvd_fb_key[1] < r or self._rsvd_fb_key[2] < nnz_cap:
+            if self._rsvd_fb is not None:
+                call("mused_rsvd_destroy", self._rsvd_fb)
+            h = C.c_void_p()
+            call("mused_rsvd_create", max(n, self.n_max), r, nnz_cap, 0, C.byref(h))
+            call("mused_rsvd_set_mode", h, 2)
+            self._rsvd_fb, self._rsvd_fb_key = h, (max(n, self.n_max), r, nnz_cap)
+        return self._rsvd_fb
 
     def svd_reduce(self, adj: Adjacency, reduced_dim: int, seed: int, n_iter: int = 5, n_oversamples: int = 10,
                    nnz_cap: int | None = None, want_components: bool = False, want_flags: bool = False):
@@ -340,10 +360,21 @@ class WindowEngine:
         comp = torch.empty((n, n_comp), dtype=torch.float64, device=self.device) if want_components else None
         call("mused_rsvd_reduce", h, n, n_comp, r, n_iter, ptr(emb), ptr(sig), ptr(comp) if want_components else None,
              stream_ptr())
+        flags = torch.empty(4, dtype=torch.int32, device=self.device)
+        _hip_memcpy_d2d(flags.data_ptr(), _lib.lib().mused_rsvd_flags(h), 16)
+        if self.rsvd_mode == "cholqr" and int(flags[2].item()) != 0:
+            # (one small blocking read per window, behind the eigenstep.)  A Cholesky pivot of the final basis was weak:
+            # the panel is numerically rank deficient (few non-empty rows) -- repeat on the reference's chain
+            self.rsvd_fallbacks += 1
+            hf = self._rsvd_fallback_handle(n, r, nnz_cap)
+            q0_dev = torch.from_numpy(np.random.RandomState(seed).normal(size=(n, r))).to(self.device)
+            call("mused_rsvd_set_q0", hf, ptr(q0_dev), n, r, stream_ptr())
+            _hip_memcpy_d2d(_lib.lib().mused_rsvd_mask_buffer(hf), adj.mask.data_ptr(), nbytes)
+            call("mused_rsvd_reduce", hf, n, n_comp, r, n_iter, ptr(emb), ptr(sig),
+                 ptr(comp) if want_components else None, stream_ptr())
+            _hip_memcpy_d2d(flags.data_ptr(), _lib.lib().mused_rsvd_flags(hf), 16)
         out = (emb, sig, comp) if want_components else (emb, sig)
         if want_flags:
-            flags = torch.empty(4, dtype=torch.int32, device=self.device)
-            _hip_memcpy_d2d(flags.data_ptr(), _lib.lib().mused_rsvd_flags(h), 16)
             out = out + (flags,)
         return out
 
@@ -365,6 +396,9 @@ class WindowEngine:
         if self._rsvd is not None:
             call("mused_rsvd_destroy", self._rsvd)
             self._rsvd = None
+        if self._rsvd_fb is not None:
+            call("mused_rsvd_destroy", self._rsvd_fb)
+            self._rsvd_fb = None
 
     def __del__(self):
         try:

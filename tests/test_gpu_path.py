@@ -492,12 +492,23 @@ def test_rsvd_rank_deficient_adjacency_matches_oracle(eng):
     adj = mo.adjacency_on_device(Xs, "", 5, engine=eng)
     _, sig_d = eng.svd_reduce(adj, 20, 3)
     np.testing.assert_allclose(sig_d.cpu().numpy(), sig_o, rtol=0, atol=1e-8 * sig_o[0])
+    assert eng.rsvd_fallbacks >= 1  # the window went through the LU / Householder handle
     # and a full-rank window right after it on the same handle (flag cleared per call)
+    fb = eng.rsvd_fallbacks
     X = rng.standard_normal((400, 12))
     A2 = omo.create_adjacency_matrix(X, "", 10)
     _, s2o, _ = omo.randomized_svd_reduce(A2, 20, 3)
     _, s2d = eng.svd_reduce(mo.adjacency_on_device(X, "", 10, engine=eng), 20, 3)
     np.testing.assert_allclose(s2d.cpu().numpy(), s2o, rtol=1e-9)
+    assert eng.rsvd_fallbacks == fb
+    # the in-graph fallback (mode 0, what a bare C-ABI caller gets) on the rank-deficient window
+    from mused_amd.engine import WindowEngine
+
+    e0 = WindowEngine(400)
+    e0.rsvd_mode = "graph"
+    _, sig_g = e0.svd_reduce(mo.adjacency_on_device(Xs, "", 5, engine=e0), 20, 3)
+    np.testing.assert_allclose(sig_g.cpu().numpy(), sig_o, rtol=0, atol=1e-8 * sig_o[0])
+    e0.close()
 
 
 def test_rsvd_edge_overflow_is_flagged_and_memory_safe(eng):
