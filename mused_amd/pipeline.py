@@ -50,8 +50,9 @@ class StreamPipeline:
         # launches that leaves most of the GPU idle (25 ms of latency, a few per cent of its throughput); windows are
         # independent until the label chain, so consecutive windows go to `window_slots` engines on their own streams
         # (each driven by its own host thread: launching the 1,600-node graph costs ~20 ms of host time) and overlap.
-        # Measured at config 2: 29 -> 15.6 ms per window with 6 slots (340 k -> 640 k rows/s); 2 slots are slower than
-        # one (37-40 ms), 4 vary between runs (hardware-queue sharing).  Opt-in (default 1; MUSED_WINDOW_SLOTS for
+        # Measured at config 2 (Cholesky-QR eigenstep): 12.6 -> 6.6 ms per window with 4 slots (792 k -> 1.52 M rows/s);
+        # 2 slots can be slower than one, the best count varies with how HIP maps the streams onto hardware queues.
+        # Opt-in (default 1; MUSED_WINDOW_SLOTS for
         # process_streaming_data).  The sketch approaches carry state from window to window and keep one slot.
         self._nslots = max(1, int(window_slots)) if (approach != "SWFDMC" and not feature_sketch) else 1
         # every engine records its eigenstep graph ONCE, in the caller's thread, before the slot threads exist (see
