@@ -93,28 +93,51 @@ __global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ G,
   if (t == 0) s_delta = 16.0 * r * 2.220446049250313e-16 * fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   __syncthreads();
   const double delta = s_delta;
-  for (int j = 0; j < r; ++j) {
-    const double piv0 = Lp[tri_at(j, j)];
-    // a pivot below 1e-11 of the largest diagonal entry: Y is (numerically) rank deficient or worse conditioned than 3e5 --
-    // fine for a normaliser, not for the final orthonormal basis (the caller then runs the Householder chain)
-    if (weak_flag && t == 0 && !(piv0 > 1e-11 * (delta / (16.0 * r * 2.220446049250313e-16)))) *weak_flag = 1;
-    const double piv = piv0 + delta;  // the same (final) value for every thread
-    const double d = sqrt(piv > delta ? piv : delta);
-    const double inv = 1.0 / d;
-    __syncthreads();  // all have read the pivot
-    if (t == 0) Lp[tri_at(j, j)] = d;
-    for (int i = j + 1 + t; i < r; i += 256) Lp[tri_at(i, j)] *= inv;
-    __syncthreads();
-    for (int i = j + 1 + ti; i < r; i += 16) {  // L[i][k] -= L[i][j] L[k][j], j < k <= i
-      const double lij = Lp[tri_at(i, j)];
-      double* row = Lp + tri_at(i, 0);
-      int k = j + 1 + tk;
-      for (; k + 48 <= i; k += 64) {  // four entries per pass: their LDS reads are in flight together
-        const double a0 = row[k], a1 = row[k + 16], a2 = row[k + 32], a3 = row[k + 48];
-        const double b0 = Lp[tri_at(k, j)], b1 = Lp[tri_at(k + 16, j)], b2 = Lp[tri_at(k + 32, j)], b3 = Lp[tri_at(k + 48, j)];
-        row[k] = a0 - lij * b0; row[k + 16] = a1 - lij * b1; row[k + 32] = a2 - lij * b2; row[k + 48] = a3 - lij * b3;
+  const double weak = 1e-11 * (delta / (16.0 * r * 2.220446049250313e-16));
+  // Blocked right-looking factorisation, panels of 8 columns: inside a panel a column step only touches the panel's own
+  // columns; the rest of the matrix gets ONE rank-8 update per panel (8 FMAs per entry and LDS pass instead of 8 passes).
+  for (int jb = 0; jb < r; jb += 8) {
+    const int pw = (r - jb) < 8 ? (r - jb) : 8;
+    for (int p = 0; p < pw; ++p) {
+      const int j = jb + p;
+      const double piv0 = Lp[tri_at(j, j)];  // the same (final) value for every thread
+      // a pivot below 1e-11 of the largest diagonal entry: Y is (numerically) rank deficient or worse conditioned than 3e5
+      // -- fine for a normaliser, not for the final orthonormal basis (the caller then falls back to Householder QR)
+      if (weak_flag && t == 0 && !(piv0 > weak)) *weak_flag = 1;
+      const double piv = piv0 + delta;
+      const double d = sqrt(piv > delta ? piv : delta);
+      const double inv = 1.0 / d;
+      __syncthreads();  // all have read the pivot
+      if (t == 0) Lp[tri_at(j, j)] = d;
+      for (int i = j + 1 + t; i < r; i += 256) Lp[tri_at(i, j)] *= inv;
+      __syncthreads();
+      const int nc = jb + pw - 1 - j;  // panel columns still to be updated by column j
+      if (nc > 0) {
+        const int tot = (r - j - 1) * nc;
+        for (int e = t; e < tot; e += 256) {
+          const int q = e / nc, c = j + 1 + (e - q * nc), i = j + 1 + q;
+          if (i >= c) Lp[tri_at(i, c)] -= Lp[tri_at(i, j)] * Lp[tri_at(c, j)];
+        }
       }
-      for (; k <= i; k += 16) row[k] -= lij * Lp[tri_at(k, j)];
+      __syncthreads();
+    }
+    const int j1 = jb + pw;
+    for (int i = j1 + ti; i < r; i += 16) {  // rank-pw update of the trailing block, dealt to a 16 x 16 thread grid
+      const double* ri = Lp + tri_at(i, jb);
+      double li[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) li[p] = p < pw ? ri[p] : 0.0;
+      double* row = Lp + tri_at(i, 0);
+      for (int k = j1 + tk; k <= i; k += 16) {
+        const double* rk = Lp + tri_at(k, jb);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; p += 2) {
+          if (p < pw) s0 = fma(li[p], rk[p], s0);
+          if (p + 1 < pw) s1 = fma(li[p + 1], rk[p + 1], s1);
+        }
+        row[k] -= s0 + s1;
+      }
     }
     __syncthreads();
   }
