@@ -298,21 +298,25 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
     const int nsp = cdiv(n, CHOLQR_KCHUNK);
     const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
     const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(r | 1);
-    // Y = (A | A^T) Q in Qa;  G = Y^T Y in U;  L = chol(G + delta I) packed in Cm;  Q = Y L^-T in Qb
-    auto normalise = [&]() -> int {
+    // G = Y^T Y in U;  L = chol(G + delta I) packed in Cm;  dst = Y L^-T
+    auto normalise = [&](const double* Y, double* dst) -> int {
       int e;
-      if ((e = gemm_f64_splitk(false, false, h->Qa, ld, h->Qa, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st))) return e;
+      if ((e = gemm_f64_splitk(false, false, Y, ld, Y, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st))) return e;
       hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)r * r, 256)), dim3(256), 0, st, h->gpart, nsp, r, h->U);
       hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, r, h->Cm, (int*)nullptr);
-      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, h->Qa, ld, n, r, h->Cm, h->Qb, ld);
+      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, Y, ld, n, r, h->Cm, dst, ld);
       return MUSED_OK;
     };
+    // ONE normalisation per power iteration, of A^T (A Q): the two products in a row square the spread of the basis
+    // ((sigma_1 / sigma_r)^2 ~ 1e3 .. 1e4 for these adjacency matrices), far inside what a Cholesky of the Gram takes
+    // (1e-11 of the largest pivot is the alarm level), and the subspace is the same (goldens: sigma 1e-15, labels equal)
     for (int it = 0; it < n_iter; ++it) {
-      RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
-      RC(normalise());
-      RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qb, ld, rc, h->Qa, ld, st));
-      RC(normalise());
-      Qcur = h->Qb;
+      double* X = (Qcur == h->Qa) ? h->Qb : h->Qa;
+      RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, X, ld, st));
+      double* Z = (X == h->Qa) ? h->Qb : h->Qa;  // (the buffer of the old basis, unless that is Q0)
+      RC(spmm_binary(h->rowptrT, h->colidxT, n, X, ld, rc, Z, ld, st));
+      RC(normalise(Z, X));
+      Qcur = X;
     }
   } else {
     for (int it = 0; it < n_iter; ++it) {
@@ -324,16 +328,18 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
       Qcur = h->Qb;
     }
   }
-  RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, h->Qa, ld, st));
+  double* Yf = (Qcur == h->Qa) ? h->Qb : h->Qa;  // Y = A Q of the last step
+  double* Yt = (Yf == h->Qa) ? h->Qb : h->Qa;
+  RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, Yf, ld, st));
   rc = n < rc ? n : rc;
   if (cholqr) {
-    // final orthonormal basis: Cholesky-QR twice (Qa -> Qb -> Qf); a weak pivot in either pass raises flags[2] and the
-    // Householder chain below (otherwise a string of no-op launches) recomputes Qf from the untouched Y in Qa
+    // final orthonormal basis: Cholesky-QR twice (Yf -> Yt -> Qf); a weak pivot in either pass raises flags[2] (mode 0:
+    // the Householder chain below, otherwise a string of no-op launches, then recomputes Qf from the untouched Yf)
     const int nsp = cdiv(n, CHOLQR_KCHUNK);
     const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
     const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(r | 1);
-    const double* src = h->Qa;
-    double* dsts[2] = {h->Qb, h->Qf};
+    const double* src = Yf;
+    double* dsts[2] = {Yt, h->Qf};
     for (int pass = 0; pass < 2; ++pass) {
       RC(gemm_f64_splitk(false, false, src, ld, src, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st));
       hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)r * r, 256)), dim3(256), 0, st, h->gpart, nsp, r, h->U);
@@ -341,9 +347,9 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
       hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, src, ld, n, r, h->Cm, dsts[pass], ld);
       src = dsts[pass];
     }
-    if (h->mode == 0) RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st, h->flags + 2));
+    if (h->mode == 0) RC(qr_economic(Yf, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st, h->flags + 2));
   } else {
-    RC(qr_economic(h->Qa, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st));
+    RC(qr_economic(Yf, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st));
   }
   RC(spmm_binary(h->rowptrT, h->colidxT, n, h->Qf, ld, rc, h->Bt, ld, st));
 
