@@ -50,7 +50,7 @@ class StreamPipeline:
         # launches that leaves most of the GPU idle (25 ms of latency, a few per cent of its throughput); windows are
         # independent until the label chain, so consecutive windows go to `window_slots` engines on their own streams
         # (each driven by its own host thread: launching the 1,600-node graph costs ~20 ms of host time) and overlap.
-        # Measured at config 2 (Cholesky-QR eigenstep): 12.6 -> 6.6 ms per window with 4 slots (792 k -> 1.52 M rows/s);
+        # Measured at config 2 (Cholesky-QR eigenstep): 9.9 -> 6.6 ms per window with 4 slots (1.01 M -> 1.5 M rows/s);
         # 2 slots can be slower than one, the best count varies with how HIP maps the streams onto hardware queues.
         # Opt-in (default 1; MUSED_WINDOW_SLOTS for
         # process_streaming_data).  The sketch approaches carry state from window to window and keep one slot.
