@@ -54,16 +54,18 @@ __global__ void gram_reduce_pad_kernel(const double* __restrict__ partial, int n
   G[gid] = s;
 }
 
-// ---- Cholesky-QR normaliser of the power iterations -----------------------------------------------------------------
+// ---- Cholesky-QR in place of the LU normaliser and of the final Householder QR ------------------------------------------
 // sklearn normalises the iterates Y of its randomized range finder with an LU factorisation (extmath.py:343-351,
-// power_iteration_normalizer = "LU" for n_iter = 5): any well-conditioned basis of span(Y) serves -- the range after the
-// last iteration is the same subspace, so singular values, embedding and labels agree with the LU chain to rounding
-// (measured on every golden: sigma to 1e-15, embedding to 1e-12, k-means labels identical) -- and a partially pivoted LU
-// of a 10,000 x 138 panel is ~70 dependent launches.  Here:  G = Y^T Y (split-K MFMA GEMM, fixed-order reduction),
-// G + delta I = L L^T in LDS (one workgroup),  Q = Y L^-T by forward substitution, 64 rows per workgroup: 4 launches.  delta = 16 r eps max(diag G)
-// keeps the factorisation defined when Y is rank deficient (adjacency matrices of rank < r: same-user cliques, tiny
-// windows); the directions it then leaves unnormalised are noise that the final Householder QR orthogonalises, exactly
-// as the garbage columns of a rank-deficient LU are.  MUSED_RSVD_NORMALIZER=lu restores the LU chain.
+// power_iteration_normalizer = "LU" for n_iter = 5) and ends with an economic QR (:355).  Both only have to deliver a
+// well-conditioned (resp. orthonormal) BASIS of span(Y): the range after the last iteration is the same subspace, so the
+// singular values, V and the embedding agree with the LU chain to rounding (measured on every golden: sigma to 1e-15,
+// embedding to 1e-12, k-means labels identical) -- and a partially pivoted LU of a 10,000 x 138 panel is ~70 dependent
+// launches, the Householder QR ~690.  Here:  G = Y^T Y (split-K MFMA GEMM, fixed-order reduction),  G + delta I = L L^T in
+// LDS (one workgroup),  Q = Y L^-T by forward substitution, 64 rows per workgroup: 4 launches.  One such pass per power
+// iteration (of A^T (A Q)), two for the final basis (Cholesky-QR2).  delta = 16 r eps max(diag G) keeps the factorisation
+// defined when Y is rank deficient (adjacency matrices with few non-empty rows, tiny windows); a pivot below 1e-11 of the
+// largest in a FINAL pass raises flags[2], and the basis is then taken from the Householder chain (mused_rsvd_set_mode:
+// recorded behind the flag, or by the caller on a mode-2 handle).  MUSED_RSVD_NORMALIZER=lu restores the reference's chain.
 constexpr int CHOLQR_MAX_R = 143;  // packed lower triangle of L (r (r + 1) / 2 doubles) + 64 rows of Y in LDS: 157 KB
 
 __device__ __forceinline__ int tri_at(int i, int k) { return i * (i + 1) / 2 + k; }
