@@ -131,7 +131,8 @@ int mused_rsvd_set_q0(void* handle, const double* Q0, int n, int r, void* stream
 int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double* out_embed, double* out_sigma,
                       double* out_components, void* stream);
 /* device int[4] raised by mused_rsvd_reduce (flags[0] != 0: more than nnz_cap edges -> lists truncated, result
- * invalid but memory-safe); copy it on the same stream behind the call for a sync-free check */
+ * invalid but memory-safe; flags[2]: weak Cholesky pivot, see mused_rsvd_set_mode; flags[3] != 0: the r x r eigensolve
+ * gave up (work-queue timeout), result invalid); copy it on the same stream behind the call for a sync-free check */
 const int* mused_rsvd_flags(void* handle);
 /* How the eigenstep builds its bases.  0 (default): Cholesky-QR (Gram + Cholesky + triangular solve) with the
  * Householder chain recorded behind a weak-pivot flag: self-contained.  1: Cholesky-QR only -- flags[2] != 0 (third int of
@@ -191,6 +192,9 @@ int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, lo
  * out_info (lanes x 2 = {level, delta}, may be NULL) */
 int mused_swfd_query(void* handle, double* out_sketch, double* out_sigma, double* out_info, void* stream);
 int mused_swfd_counters(void* handle, long* rows_seen, int* pending); /* HOST outputs */
+/* BLOCKING (synchronises `stream`): *status_out (HOST) != 0 -> an eigensolve of this sketch gave up (bit 0: timeout of the
+ * persistent work-queue solver); everything it has returned since is invalid.  Sticky. */
+int mused_swfd_status(void* handle, int* status_out, void* stream);
 /* state exchange between ranks (one half = the L sketches of kind 0 MAIN / 1 AUX) */
 long mused_swfd_half_bytes(void* handle);
 int mused_swfd_export_half(void* handle, int kind, void* dst, void* stream);

@@ -72,6 +72,7 @@ _PROTOS = {
     "mused_swfd_append": (_i, [_vp, _vp, _i, _l, _l, _vp]),
     "mused_swfd_query": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mused_swfd_counters": (_i, [_vp, C.POINTER(_l), C.POINTER(_i)]),
+    "mused_swfd_status": (_i, [_vp, C.POINTER(_i), _vp]),
     "mused_swfd_half_bytes": (_l, [_vp]),
     "mused_swfd_export_half": (_i, [_vp, _i, _vp, _vp]),
     "mused_swfd_import_half": (_i, [_vp, _i, _vp, _vp]),

@@ -2,14 +2,16 @@
 // rotation (the "per-window SVD/rotation step" of SWFD), the <= 4l x 4l Gram of a sketch query and the
 // (l + 10) x (l + 10) Gram of the randomized-SVD projection B = Q^T A.  One-sided (Hestenes) block Jacobi in fp64,
 // register resident, orders up to 1024 -- as a hipGraph of block-pair rounds or as one persistent work-queue launch.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "internal.h"
 
 namespace mused {
 
-std::mutex& capture_mutex() {
-  static std::mutex m;
+std::recursive_mutex& capture_mutex() {
+  static std::recursive_mutex m;
   return m;
 }
 
@@ -39,6 +41,8 @@ struct EigPlan {
   unsigned* q;        // unit ring: 0 = empty, else 1 + ((matrix * 256 + global round) * 4 + block pair)
   unsigned qcap;
   struct OsjqCtl* qctl;
+  unsigned long long q_timeout;  // ticks of s_memrealtime (100 MHz) a consumer waits for its ticket (3 s; MUSED_EIG_QUEUE_TIMEOUT_TICKS)
+  int* err_out;                  // optional device word the caller reads back: set when the queue solver gave up (results invalid)
   int* qdone;         // per matrix: units of its current round that have finished
   double* trace; // OSJ adaptive: trace(G) per matrix (owns the allocation notconv / work point into)
   unsigned long long* work;  // OSJ adaptive, profiling: (matrix, sweep) pairs that did work
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
                                                      int sort_from, int* __restrict__ notconv,
                                                      const double* __restrict__ trace, unsigned* __restrict__ q,
                                                      unsigned qcap, OsjqCtl* __restrict__ ctl, int* __restrict__ qdone,
-                                                     int* __restrict__ qclean) {
+                                                     int* __restrict__ qclean, unsigned long long timeout) {
   __shared__ OsjwShared<RP, 8> sh;
   __shared__ unsigned s_item;
   const int rounds = nb - 1, upr = nb / 2;
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
             break;
           }
           __builtin_amdgcn_s_sleep(4);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {  // 3 s: give up, tell everyone
+          if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {  // (3 s by default) give up, tell everyone
             __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             item = OSJQ_EXIT;
@@ -903,6 +907,11 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
   }
 }
 
+// after the persistent launch: a timeout inside it leaves partially rotated matrices behind -- tell the caller's status word
+__global__ void osjq_error_kernel(const OsjqCtl* __restrict__ ctl, int* __restrict__ err_out) {
+  if (ctl->error) atomicOr(err_out, 1);
+}
+
 __global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) q[i] = 0u;
@@ -918,7 +927,8 @@ static void osjq_launch(EigPlan* p, hipStream_t st) {
   long units = (long)p->batch * upr;
   const int grid = (int)(units < 512 ? units : 512);  // 2 resident workgroups per CU; fewer than that is fine too
   hipLaunchKernelGGL((osjq_kernel<RP>), dim3(grid), dim3(256), 0, st, p->Gc, p->ldn, nb, p->batch, p->sweeps, p->sort_from,
-                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone, p->qclean);
+                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone, p->qclean, p->q_timeout);
+  if (p->err_out) hipLaunchKernelGGL(osjq_error_kernel, dim3(1), dim3(1), 0, st, p->qctl, p->err_out);
 }
 
 // orders <= 256: round 0 carries the pairs inside the blocks, nb - 1 launches per sweep
@@ -1083,13 +1093,15 @@ static int osj_padded_order(int n) {
   return ((n + 127) / 128) * 128;
 }
 
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep, int flags) {
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep, int flags, int* err_out) {
   MUSED_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024 && batch >= 1 && sweeps >= 1,
                 "eig_plan_create: the order must be even and <= 1024 (n=%d)", n);
+  CaptureLock resource_guard(capture_mutex());  // allocations + capture: not beside another thread's capture
   EigPlan* p = new EigPlan();
   memset(p, 0, sizeof(*p));
   p->n = n; p->batch = batch; p->sweeps = sweeps;
   p->rep = rep;
+  p->err_out = err_out;
   p->method = 1;
   const size_t bytes = sizeof(double) * (size_t)batch * n * n;
   if (p->method == 1) {
@@ -1130,6 +1142,8 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         MUSED_CHECK_HIP(hipMalloc(&p->qdone, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMalloc(&p->qclean, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMemset(p->qctl, 0, sizeof(OsjqCtl)));
+        const char* tq = getenv("MUSED_EIG_QUEUE_TIMEOUT_TICKS");  // test knob: 1 forces the give-up path
+        p->q_timeout = tq ? strtoull(tq, nullptr, 10) : 300000000ull;
       }
     }
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
@@ -1148,7 +1162,6 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
   const char* ng = getenv("MUSED_NO_GRAPH");
   if (own_graph && !(ng && ng[0] == '1')) {
     MUSED_CHECK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
-    std::lock_guard<std::mutex> capture_guard(capture_mutex());
     MUSED_CHECK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
     const int rc = osj_enqueue_sweeps(p, p->cap_stream);
     hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph);
@@ -1169,6 +1182,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
 
 void eig_plan_destroy(EigPlan* p) {
   if (!p) return;
+  CaptureLock resource_guard(capture_mutex());
   if (p->have_graph) {
     (void)hipGraphExecDestroy(p->exec);
     (void)hipGraphDestroy(p->graph);

@@ -13,8 +13,13 @@ int select_from_tag_sets(const int* rowptr, const int* tags, const int* postptr,
                          int* out_idx, unsigned long long* out_mask, int mask_words, hipStream_t stream);
 int select_max_fused_rows(bool tag_sets);
 
-// hipGraph stream captures of this library are serialised across host threads (see pipeline.py: window slots)
-std::mutex& capture_mutex();
+// One process-wide lock around every stream capture of this library AND around the calls that create or release HIP
+// resources next to one (handle / plan creation and destruction: hipMalloc, hipFree, hipGraph(Exec)Destroy,
+// hipStreamCreate / Destroy, hipFuncSetAttribute).  Round 2 locked only Begin..EndCapture; a handle re-created on one host
+// thread then ran those calls beside another thread's capture (gpurun_out/r2_gputest23.log; tools/repro_capture_threads.hip
+// asks the runtime which of them a ThreadLocal capture survives).  Recursive: creation paths nest (rsvd -> eig plan).
+std::recursive_mutex& capture_mutex();
+using CaptureLock = std::lock_guard<std::recursive_mutex>;
 
 
 // C[z] = alpha * opA(A[z]) * opB(B[z]); fp64 in / fp64 out, MFMA f64 16x16x4.
@@ -57,8 +62,11 @@ struct EigPlan;
 // captures a larger pipeline that contains this solve).
 constexpr int EIG_PLAN_FIXED_SWEEPS = 1;  // always `sweeps` sweeps (no convergence flags)
 constexpr int EIG_PLAN_NO_SORT = 2;       // no column sorting: column j of the result descends from column j of the input
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr, int flags = 0);
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr, int flags = 0,
+                    int* err_out = nullptr);
 // rep (device, batch ints, optional, read at every solve): matrix b is solved only when rep[b] == b
+// err_out (device int, optional): OR-ed with 1 by a solve of the persistent work-queue solver that gave up waiting
+// (timeout: the matrices are left partially rotated and the results of that solve are invalid)
 void eig_plan_destroy(EigPlan* p);
 // In: G (batch x n x n, symmetric) is copied into the plan's workspace.  Out: eigenvalues
 // (unsorted, batch x n) and eigenvectors V (batch x n x n, column j <-> eigenvalue j).

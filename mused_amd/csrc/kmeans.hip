@@ -58,13 +58,11 @@ __global__ __launch_bounds__(KM_CHUNK) void km_assign_kernel(const double* __res
   double* sC = km_lds;                  // [k][d]
   double* sS = km_lds + (long)k * d;    // [k][d]
   int* sL = reinterpret_cast<int*>(sS + (long)k * d);  // [KM_CHUNK]
-  int* sN = sL + KM_CHUNK;                             // [k]
   const int t = threadIdx.x, r0 = blockIdx.x * KM_CHUNK;
   for (int e = t; e < k * d; e += KM_CHUNK) {
     sC[e] = C[e];
     sS[e] = 0.0;
   }
-  for (int j = t; j < k; j += KM_CHUNK) sN[j] = 0;
   __syncthreads();
   const int row = r0 + t;
   int lab = -1;
@@ -94,10 +92,10 @@ __global__ __launch_bounds__(KM_CHUNK) void km_assign_kernel(const double* __res
       sS[(long)j * d + c] += Xc[(long)(r0 + r) * d + c];
     }
   }
-  if (t < k) {
+  for (int j = t; j < k; j += KM_CHUNK) {  // k may exceed the chunk (k <= 1024, k * d <= 8192)
     int cnt = 0;
-    for (int r = 0; r < rows; ++r) cnt += (sL[r] == t);
-    pcnt[(long)blockIdx.x * k + t] = cnt;
+    for (int r = 0; r < rows; ++r) cnt += (sL[r] == j);
+    pcnt[(long)blockIdx.x * k + j] = cnt;
   }
   __syncthreads();
   for (int e = t; e < k * d; e += KM_CHUNK) psum[(long)blockIdx.x * k * d + e] = sS[e];

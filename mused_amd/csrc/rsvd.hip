@@ -394,6 +394,7 @@ int mused_rsvd_destroy(void* handle);
 
 int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** out) {
   MUSED_REQUIRE(out && n_max >= 2 && r_max >= 1 && r_max <= 1022 && nnz_cap >= 1, "mused_rsvd_create: bad arguments");
+  CaptureLock resource_guard(capture_mutex());
   Rsvd* h = new Rsvd();
   memset(h, 0, sizeof(*h));
   const int rc = rsvd_create_impl(h, n_max, r_max, nnz_cap, sweeps);
@@ -429,7 +430,8 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
   ALLOC(h->evals, 8 * (size_t)h->eig_n); ALLOC(h->U, 8 * (size_t)h->eig_n * h->eig_n);
   ALLOC(h->Cm, 8 * (size_t)r_max * r_max); ALLOC(h->sigma, 8 * (size_t)r_max); ALLOC(h->signs, 8 * (size_t)r_max);
 #undef ALLOC
-  int rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig);
+  // flags[3]: the r x r eigensolve gave up (work-queue timeout, eig.hip) -> the result of that call is invalid
+  int rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig, nullptr, 0, h->flags + 3);
   if (rc) return rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
   {
@@ -452,6 +454,7 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
 int mused_rsvd_destroy(void* handle) {
   Rsvd* h = (Rsvd*)handle;
   if (!h) return MUSED_OK;
+  CaptureLock resource_guard(capture_mutex());
   rsvd_drop_graph(h);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   eig_plan_destroy(h->eig);
@@ -494,10 +497,10 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
   int rc;
   if (h->use_graph && h->mode != 2) {
     if (!h->have_graph || h->g_n != n || h->g_r != r || h->g_ncomp != n_comp || h->g_iter != n_iter) {
+      CaptureLock capture_guard(capture_mutex());  // one capture at a time, and no resource call of this library beside it
       rsvd_drop_graph(h);
       // the capture stream lives only while it records: every live HIP stream competes for the hardware queues
       if (!h->cap_stream) MUSED_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-      std::lock_guard<std::mutex> capture_guard(capture_mutex());  // one capture at a time in the process
       MUSED_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
       rc = rsvd_enqueue(h, n, r, n_comp, n_iter, h->cap_stream, true);
       hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
@@ -531,13 +534,15 @@ int mused_rsvd_reduce(void* handle, int n, int n_comp, int r, int n_iter, double
 int mused_rsvd_set_mode(void* handle, int mode) {
   Rsvd* h = (Rsvd*)handle;
   MUSED_REQUIRE(h && mode >= 0 && mode <= 2, "mused_rsvd_set_mode: bad arguments");
+  CaptureLock resource_guard(capture_mutex());
   if (h->mode != mode) rsvd_drop_graph(h);
   h->mode = mode;
   return MUSED_OK;
 }
 
 // Device int[4] the eigenstep raises its flags in (flags[0] != 0: the adjacency had more than nnz_cap edges, the
-// neighbour lists were truncated and the result of that mused_rsvd_reduce is INVALID).  Rewritten by every
+// neighbour lists were truncated and the result of that mused_rsvd_reduce is INVALID; flags[2]: weak Cholesky pivot, see
+// mused_rsvd_set_mode; flags[3] != 0: the r x r eigensolve timed out, result INVALID).  Rewritten by every
 // mused_rsvd_reduce on its stream: copy it behind the call (same stream) to read it without a host sync.
 const int* mused_rsvd_flags(void* handle) { return handle ? ((Rsvd*)handle)->flags : nullptr; }
 

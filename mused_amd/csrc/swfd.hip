@@ -45,6 +45,7 @@ struct Swfd {
   int* plan;      // S x ell x 2  {kind (0 none, 1 keep, 2 dump), position}
   int* keep_src;  // S x ell      buffer position -> row of T
   long long* now_dev;
+  int* status;  // device word, sticky: bit 0 = an eigensolve of this sketch gave up (work-queue timeout): results invalid
   EigPlan* eig;
   // query workspace
   double *stack, *evals_q, *Uq, *Wq, *Bout, *sig_out, *qinfo;
@@ -650,6 +651,7 @@ int mused_swfd_create_lanes(long N, double R, int d, int ell, int sweeps, int la
   MUSED_REQUIRE(out && N >= 1 && d >= 1 && ell >= 1 && ell <= 256, "mused_swfd_create: need N, d >= 1 and 1 <= sketch_dim <= 256");
   MUSED_REQUIRE(lanes >= 1 && lanes <= 64, "mused_swfd_create_lanes: 1 <= lanes <= 64");
   MUSED_REQUIRE(N < (1l << 31), "mused_swfd_create: N too large");
+  CaptureLock resource_guard(capture_mutex());  // allocations + the plans' captures: not beside another thread's capture
   Swfd* h = new Swfd();
   memset(h, 0, sizeof(*h));
   const int rc = swfd_create_impl(h, N, R, d, ell, sweeps, lanes);
@@ -692,6 +694,7 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
     h->skip_dead = (sd && sd[0] == '0') ? 0 : 1;
   }
   ZALLOC(h->dropped, 8 * S);
+  ZALLOC(h->status, 4);
   ALLOC(h->theta, 8 * S);
   ALLOC(h->T, 8 * S * l * dd); ALLOC(h->Wc, 8 * S * l * n2); ALLOC(h->evals, 8 * S * n2); ALLOC(h->U, 8 * S * n2 * n2);
   ALLOC(h->plan, 4 * S * l * 2); ALLOC(h->keep_src, 4 * S * l); ALLOC(h->now_dev, 8);
@@ -708,9 +711,9 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
   MUSED_CHECK_HIP(hipMemcpy(h->theta, th.data(), 8 * S, hipMemcpyHostToDevice));
   int rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
-  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep))) return rc;
-  if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq))) return rc;
-  if (h->n3 < h->n4 && (rc = eig_plan_create(h->n3, lanes, h->sweeps + 2, true, &h->eigq3))) return rc;
+  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep, 0, h->status))) return rc;
+  if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq, nullptr, 0, h->status))) return rc;
+  if (h->n3 < h->n4 && (rc = eig_plan_create(h->n3, lanes, h->sweeps + 2, true, &h->eigq3, nullptr, 0, h->status))) return rc;
   {
     // input-block pre-rotation (swfd_prerotate): batches of `pre_chunk` blocks x lanes, workspace <= ~256 MB per array
     const char* pr = getenv("MUSED_SWFD_PREROT");
@@ -727,7 +730,7 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
       const char* ps = getenv("MUSED_SWFD_PREROT_SWEEPS");
       const int psw = ps ? atoi(ps) : 5;
       if ((rc = eig_plan_create(h->n2, (int)c * lanes, psw > 0 ? psw : 5, true, &h->eigp, nullptr,
-                                EIG_PLAN_FIXED_SWEEPS | EIG_PLAN_NO_SORT)))
+                                EIG_PLAN_FIXED_SWEEPS | EIG_PLAN_NO_SORT, h->status)))
         return rc;
     }
   }
@@ -737,13 +740,14 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
 int mused_swfd_destroy(void* handle) {
   Swfd* h = (Swfd*)handle;
   if (!h) return MUSED_OK;
+  CaptureLock resource_guard(capture_mutex());
   eig_plan_destroy(h->eig);
   eig_plan_destroy(h->eigq);
   if (h->eigq3) eig_plan_destroy(h->eigq3);
   if (h->eigp) eig_plan_destroy(h->eigp);
   void* bufs[] = {h->buf, h->queue, h->qt, h->meta, h->dropped, h->theta, h->T, h->Wc, h->evals, h->U, h->plan,
                   h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel,
-                  h->rep, h->pre_in, h->pre_out, h->pre_gram};
+                  h->rep, h->pre_in, h->pre_out, h->pre_gram, h->status};
   for (void* b : bufs) (void)hipFree(b);
   delete h;
   return MUSED_OK;
@@ -815,6 +819,16 @@ int mused_swfd_query(void* handle, double* out_sketch, double* out_sigma, double
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && out_sketch, "mused_swfd_query: null pointer");
   return swfd_query(h, out_sketch, out_sigma, out_info, (hipStream_t)stream);
+}
+
+// BLOCKING status read (synchronises `stream`): *status_out != 0 -> an eigensolve of this sketch gave up (bit 0: timeout of
+// the persistent work-queue solver) and everything the sketch has returned since is INVALID.  Sticky until destroy.
+int mused_swfd_status(void* handle, int* status_out, void* stream) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && status_out, "mused_swfd_status: null pointer");
+  MUSED_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  MUSED_CHECK_HIP(hipMemcpy(status_out, h->status, sizeof(int), hipMemcpyDeviceToHost));
+  return MUSED_OK;
 }
 
 int mused_swfd_counters(void* handle, long* rows_seen, int* pending) {

@@ -141,6 +141,13 @@ class WindowEngine:
         self._knn_ws = None
         self._knn_cap = 0
         self._ovf = torch.zeros(1, dtype=torch.int32, device=device)
+        # DEFERRED flags (StreamPipeline): between begin_window(defer=True) and the next begin_window the overflow word of
+        # the i-th kNN call goes to _ovf8[i] and is NOT read here -- the caller copies it to the host behind the window's
+        # event together with the eigenstep's flags and repeats a flagged window on a fallback engine (no host read on
+        # the per-window path)
+        self._ovf8 = torch.zeros(8, dtype=torch.int32, device=device)
+        self.defer = False
+        self._defer_slot = 0
         self.knn_fallbacks = 0  # windows redone on the classic path because a candidate list overflowed
         self._rsvd = None
         self._rsvd_fb = None       # fallback handle (mode 2), created on first use
@@ -162,6 +169,21 @@ class WindowEngine:
         if self._scores is None:
             self._scores = torch.empty(self.n_max * self.n_max, dtype=torch.float64, device=self.device)
         return self._scores
+
+    def begin_window(self, defer: bool):
+        """Start a window; defer=True: overflow / weak-pivot flags are left on the device for the caller (`window_flags`)."""
+        self.defer = bool(defer)
+        self._defer_slot = 0
+        if self.defer:
+            self._ovf8.zero_()
+
+    def window_flags(self, rsvd_flags) -> torch.Tensor:
+        """int32[12] device tensor = [the eigenstep's 4 flags | the overflow words of the window's kNN calls], taken on
+        the current stream (two small device-to-device copies)."""
+        out = torch.empty(12, dtype=torch.int32, device=self.device)
+        _hip_memcpy_d2d(out.data_ptr(), rsvd_flags.data_ptr(), 16)
+        _hip_memcpy_d2d(out.data_ptr() + 16, self._ovf8.data_ptr(), 32)
+        return out
 
     def _fused_ws(self, kk: int):
         # a phase admits about twice the k candidates already held (it shows twice the columns seen so far): 4 k + 128
@@ -208,13 +230,16 @@ class WindowEngine:
             fused = kk <= cap <= 1024
         if fused:
             # similarity + selection in one pass over the tiles, no n x n score matrix (knn_fused.hip)
+            deferred = self.defer and self._defer_slot < 8
+            ovf_ptr = C.c_void_p(self._ovf8.data_ptr() + 4 * self._defer_slot) if deferred else ptr(self._ovf)
             call("mused_knn_fused", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(ws), ws.numel(), cap,
-                 ptr(idx) if want_idx else None, ptr(mask), w, ptr(self._ovf), stream_ptr())
+                 ptr(idx) if want_idx else None, ptr(mask), w, ovf_ptr, stream_ptr())
             if self.score_events is not None:
                 e1.record()
                 self.score_events.append((e0, e1))
-            # one small host read per modality and window: the host stays at most one stage ahead of the device
-            if int(self._ovf.item()) != 0:
+            if deferred:
+                self._defer_slot += 1  # the caller reads the word behind the window (window_flags)
+            elif int(self._ovf.item()) != 0:  # one small blocking read: direct callers get a finished result
                 self.knn_fallbacks += 1
                 fused = False
         if not fused:
@@ -362,7 +387,7 @@ class WindowEngine:
              stream_ptr())
         flags = torch.empty(4, dtype=torch.int32, device=self.device)
         _hip_memcpy_d2d(flags.data_ptr(), _lib.lib().mused_rsvd_flags(h), 16)
-        if self.rsvd_mode == "cholqr" and int(flags[2].item()) != 0:
+        if self.rsvd_mode == "cholqr" and not self.defer and int(flags[2].item()) != 0:
             # (one small blocking read per window, behind the eigenstep.)  A Cholesky pivot of the final basis was weak:
             # the panel is numerically rank deficient (few non-empty rows) -- repeat on the reference's chain
             self.rsvd_fallbacks += 1
@@ -380,12 +405,16 @@ class WindowEngine:
 
     @staticmethod
     def check_rsvd_flags(flags) -> None:
-        """Raise if the int32[4] flag word of an eigenstep (host copy) reports truncated neighbour lists."""
+        """Raise if the flag word of an eigenstep (host copy, >= 4 ints) reports truncated neighbour lists or an
+        eigensolve that gave up."""
         if int(flags[0]) != 0:
             raise MusedError(
                 "randomized-SVD eigenstep: the fused adjacency has more edges than the nnz_cap it was given; "
                 "its neighbour lists were truncated and the embedding is invalid"
             )
+        if int(flags[3]) != 0:
+            raise MusedError("randomized-SVD eigenstep: the r x r eigensolve gave up (work-queue timeout); the embedding "
+                             "is invalid")
 
     def rsvd_status(self):
         flags, stats = (C.c_int * 1)(), (C.c_int * 4)()
@@ -401,6 +430,10 @@ class WindowEngine:
             self._rsvd_fb = None
 
     def __del__(self):
+        import sys
+
+        if sys is None or sys.is_finalizing():  # interpreter exit: the HIP runtime may already be gone -- leave the
+            return                               # handles to the process teardown instead of calling into it
         try:
             self.close()
         except Exception:

@@ -55,11 +55,24 @@ class StreamPipeline:
         # Opt-in (default 1; MUSED_WINDOW_SLOTS for
         # process_streaming_data).  The sketch approaches carry state from window to window and keep one slot.
         self._nslots = max(1, int(window_slots)) if (approach != "SWFDMC" and not feature_sketch) else 1
-        # every engine records its eigenstep graph ONCE, in the caller's thread, before the slot threads exist (see
-        # process_window): a modality without an edge bound ("username") would re-create the handle -- and re-capture,
-        # beside the HIP calls of the other threads, which ROCm 7.2 does not survive -- whenever a window has more edges
+        # Every engine records its eigenstep graph once, on the caller's thread, before the slot threads exist (see
+        # process_window).  A modality without an edge bound ("username") re-creates an engine's handle -- frees, graph
+        # destruction, allocations, a new capture -- whenever a window has more edges than the handle was sized for; the
+        # library serialises those resource calls with every capture of the process (csrc/internal.h: capture_mutex;
+        # round 2 ran them beside another slot's capture and aborted, gpurun_out/r2_gputest23.log).  Such streams still
+        # keep one slot: a re-creation stalls every slot behind that lock for tens of milliseconds.
         if any(mo.edges_per_row(t, self.k) is None for t in (modality_types or [])):
             self._nslots = 1
+        # DEFERRED FLAGS: the candidate-list overflow of the fused kNN and the weak-pivot / edge-count flags of the
+        # eigenstep are not read on the enqueueing thread; they travel to the host behind the window's event and a
+        # flagged (rare) window is repeated by the label worker on a fallback engine (classic kNN path, the reference's
+        # LU / Householder chain).  Not for the sketch approaches: the adjacency feeds a sketch that cannot be rewound.
+        self._defer = approach != "SWFDMC" and os.environ.get("MUSED_DEFER_FLAGS", "1") != "0"
+        self._fb_eng = None
+        self._fb_lock = threading.Lock()
+        self.redone_windows = 0
+        self._nnz_hint = 0         # edges of the densest window seen so far ("username": no a-priori bound)
+        self._closed = False
         self._slots = None        # [(engine, stream)], built at the first window
         self._nwin = 0
         self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)
@@ -116,10 +129,18 @@ class StreamPipeline:
         self._device = torch.cuda.current_device()  # worker threads must select it themselves
 
     # ---- device side of one window --------------------------------------------------------------
-    def window_device(self, mods, eng=None):
+    def window_device(self, mods, eng=None, defer=False):
         """mods: list of (W, d_m) float32/float64 tensors on the device.  Returns (reduced (W, m) CUDA
-        tensor, sigma CUDA tensor)."""
+        tensor, sigma CUDA tensor, flags): flags = None (sketch approaches), the eigenstep's int32[4] flag word, or with
+        `defer` the int32[12] word of `WindowEngine.window_flags` (nothing read on this thread)."""
         eng = eng or self.eng
+        eng.begin_window(defer)
+        try:
+            return self._window_device(mods, eng, defer)
+        finally:
+            eng.defer = False  # direct callers of the engine get finished results again
+
+    def _window_device(self, mods, eng, defer):
         types = self.types or [""] * len(mods)
         adjs = [self._adjacency(m, t, eng) for m, t in zip(mods, types)]
         fused = eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
@@ -150,26 +171,44 @@ class StreamPipeline:
             return reduced, sigma, None
         # edges per row: k selected (l2; the row itself is normally one of them) or k + 1 (cosine / text)
         per_row = [mo.edges_per_row(t, self.k) for t in types]
-        if any(b is None for b in per_row):  # "username": as many edges as a user has rows -> count them (blocking)
-            nnz_cap = max(int(fused.degrees()[2][1].item()), 1)
-        else:
+        if all(b is not None for b in per_row):
             nnz_cap = fused.n * sum(per_row)
+        elif defer:
+            # "username": as many edges as a user has rows.  Optimistic bound (the densest window so far, 8 per row to
+            # begin with); a window with more raises flags[0] and is repeated with its exact count by the label worker
+            nnz_cap = max(self._nnz_hint, fused.n * (8 + sum(b or 0 for b in per_row)))
+        else:  # count them (blocking)
+            nnz_cap = max(int(fused.degrees()[2][1].item()), 1)
+            self._nnz_hint = max(self._nnz_hint, nnz_cap + nnz_cap // 4)
         emb, sigma, flags = eng.svd_reduce(fused, self.ell, self.seed, nnz_cap=nnz_cap, want_flags=True)
+        if defer:
+            flags = eng.window_flags(flags)
         return emb, sigma, flags
 
     def _adjacency(self, m, t, eng=None):
         """One modality of one window -> device adjacency, with the reference's row filtering."""
         eng = eng or self.eng
         if t == "text" or t in mo._METADATA_TYPES or not isinstance(m, torch.Tensor):
-            return mo.adjacency_on_device(m, t, self.k, engine=eng)
+            # (text: thousands of documents tie at similarity 0 and overflow the candidate lists in most windows -- the
+            # overflow word is read at once there instead of repeating the whole window, TF-IDF included, afterwards)
+            was, eng.defer = eng.defer, eng.defer and t != "text"
+            try:
+                return mo.adjacency_on_device(m, t, self.k, engine=eng)
+            finally:
+                eng.defer = was
         metric = mo._metric_for(t)
         if not self.assume_finite and m.is_floating_point():
             if self._chk is None:
                 with self._pin_lock:  # slot threads may get here together
                     if self._chk is None:
                         self._chk = torch.cuda.Stream()
-            # the rows of a window are resident before the window is processed (run() uploads the stream first;
-            # process_window's callers hand over resident tensors): the check does not wait for the main stream
+            # The check runs on a side stream so that it does not wait for the previous window's device work -- but it
+            # must see the rows: the side stream waits for an event recorded on the stream this window is enqueued on
+            # (which already waits for whatever produced the rows on the caller's stream, _device_side), nothing more
+            ev = torch.cuda.Event()
+            ev.record()
+            self._chk.wait_event(ev)
+            m.record_stream(self._chk)
             with torch.cuda.stream(self._chk):
                 ok = bool(torch.isfinite(m).all().item())
             if not ok:
@@ -180,7 +219,7 @@ class StreamPipeline:
     def _cluster(self, job):
         """Independent per window: wait for the embedding, k-means (main.py:97)."""
         ev, red_pin, sig_pin, n_clusters, trigger, t_start = job[:6]
-        flag_pin, reduced_dev = job[6], job[7]
+        flag_pin, reduced_dev, mods = job[6], job[7], job[8]
         torch.cuda.set_device(self._device)
         ev.synchronize()
         reduced_host, sigma_host = red_pin.numpy().copy(), sig_pin.numpy().copy()
@@ -190,6 +229,13 @@ class StreamPipeline:
             if flag_pin is not None:
                 self._flag_pins.append(flag_pin)
         if flags_host is not None:
+            redo = len(flags_host) > 4 and (flags_host[2] != 0 or flags_host[4:].any()
+                                            or (flags_host[0] != 0 and self._optimistic_nnz()))
+            if redo:
+                # a candidate list overflowed / the final Cholesky-QR met a weak pivot / more edges than the optimistic
+                # bound: this window again, on the paths that have no such limits (rare; blocking on this worker only)
+                reduced_dev, sigma_dev, flags_host = self._redo_window(mods)
+                reduced_host, sigma_host = reduced_dev.cpu().numpy(), sigma_dev.cpu().numpy()
             WindowEngine.check_rsvd_flags(flags_host)  # raised on the label worker, surfaces in flush()
         t0 = time.perf_counter()
         if self._km_device and reduced_dev is not None and reduced_dev.dtype == torch.float64:
@@ -203,6 +249,30 @@ class StreamPipeline:
             clusters = mo.perform_clustering(reduced_host, n_clusters, self.seed)
         self.host_ms["kmeans"].append(1e3 * (time.perf_counter() - t0))
         return clusters, sigma_host
+
+    def _optimistic_nnz(self):
+        return any(mo.edges_per_row(t, self.k) is None for t in (self.types or []))
+
+    def _redo_window(self, mods):
+        """One window on the fallback engine (score-matrix kNN, LU / Householder eigenstep, exact edge count), on the
+        calling worker's stream; returns (reduced, sigma, host flags)."""
+        with self._fb_lock:
+            if self._fb_eng is None:
+                self._fb_eng = WindowEngine(self.W)
+                self._fb_eng.knn_mode = "classic"
+                self._fb_eng.rsvd_mode = "lu"
+            st = getattr(self._km_local, "stream", None)
+            if st is None:
+                st = self._km_local.stream = torch.cuda.Stream(priority=-1)
+            with torch.cuda.stream(st):
+                for m in mods:
+                    if isinstance(m, torch.Tensor):
+                        m.record_stream(st)
+                reduced, sigma, flags = self.window_device(mods, self._fb_eng, defer=False)
+                flags_host = flags.cpu().numpy()
+                st.synchronize()
+            self.redone_windows += 1
+            return reduced, sigma, flags_host
 
     def _chain(self, fut, job):
         """Sequential over windows: Hungarian matching against the previous window (main.py:105-119)."""
@@ -240,7 +310,7 @@ class StreamPipeline:
                 for m in mods:
                     if isinstance(m, torch.Tensor):
                         m.record_stream(st)
-            reduced, sigma, flags = self.window_device(mods, eng)
+            reduced, sigma, flags = self.window_device(mods, eng, defer=self._defer)
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
             red_pin, sig_pin = self._get_pins(reduced, sigma)
@@ -250,12 +320,12 @@ class StreamPipeline:
             if flags is not None:
                 with self._pin_lock:
                     flag_pin = self._flag_pins.pop() if self._flag_pins else None
-                if flag_pin is None:
-                    flag_pin = torch.empty(4, dtype=torch.int32, pin_memory=True)
+                if flag_pin is None or flag_pin.numel() != flags.numel():
+                    flag_pin = torch.empty(flags.numel(), dtype=torch.int32, pin_memory=True)
                 flag_pin.copy_(flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        return (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced)
+        return (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced, mods)
 
     def _cluster_after(self, fut_job):
         return self._cluster(fut_job.result())
@@ -308,8 +378,20 @@ class StreamPipeline:
         self._pending.append(self._pool.submit(self._chain_after, fut_cluster, fut_job))
 
     def flush(self):
+        """Wait for every window handed in so far; re-raises the first error a worker met (the remaining windows are
+        still drained, so that nothing is in flight afterwards)."""
+        first = None
         while self._pending:
-            self._pending.popleft().result()
+            try:
+                self._pending.popleft().result()
+            except BaseException as e:  # noqa: BLE001 -- re-raised below
+                first = first or e
+        if first is None:
+            for s in (self.swfd, self.fswfd):
+                if s is not None:
+                    s.check()  # an eigensolve of the sketch that gave up invalidates its results
+        if first is not None:
+            raise first
 
     def run(self, data_modalities, true_labels):
         """Stream whole modalities (host or device arrays) through the window loop; returns the
@@ -332,23 +414,55 @@ class StreamPipeline:
         return np.array(self.out)
 
     def close(self):
-        self.flush()
+        """Deterministic teardown, also after a failed flush(): workers are drained and joined first, then the device is
+        idle, then every handle this pipeline created is destroyed -- nothing is left to `__del__` / interpreter exit."""
+        if self._closed:
+            return
+        self._closed = True
+        err = None
+        try:
+            self.flush()
+        except BaseException as e:  # noqa: BLE001 -- re-raised after the teardown
+            err = e
+        for dp in (self._dpools or []):
+            dp.shutdown(wait=True)
+        self._dpools = None
         if self._pool is not None:
-            self._pool.shutdown()
-            self._kpool.shutdown()
+            self._kpool.shutdown(wait=True)
+            self._pool.shutdown(wait=True)
+        try:
+            torch.cuda.synchronize(self._device)
+        except Exception as e:  # noqa: BLE001
+            err = err or e
         for s in (self.swfd, self.fswfd):
             if s is not None:
                 s.close()
-        for dp in (self._dpools or []):
-            dp.shutdown()
-        self._dpools = None
+        self.swfd = self.fswfd = None
         for e, _ in (self._slots or [])[1:]:
             e.close()
         self._slots = None
+        if self._fb_eng is not None:
+            self._fb_eng.close()
+            self._fb_eng = None
         for lim in (self._blas_limit, self._omp_limit):
             if lim is not None:
                 lim.restore_original_limits()
         self._blas_limit = self._omp_limit = None
+        if err is not None:
+            raise err
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        else:  # the body failed: tear down, keep the body's exception
+            try:
+                self.close()
+            except BaseException:  # noqa: BLE001
+                pass
+        return False
 
 
 def process_streaming_data(results, data_modalities, modality_types, window_size, reduced_dim, k_basis, n_clusters_total,
@@ -360,10 +474,9 @@ def process_streaming_data(results, data_modalities, modality_types, window_size
     t0 = time.time_ns()
     # modality types go through unchanged: "" / anything the reference does not special-case = Euclidean kNN
     # (matrix_operations.py:112), "text" and "cosine" = the cosine kernel, the other SED2012 metadata types raise
-    pipe = StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, list(modality_types), step_window_ratio,
-                          window_slots=int(os.environ.get("MUSED_WINDOW_SLOTS", "1")))
-    clusters = pipe.run(data_modalities, np.asarray(complete_true_labels))
-    pipe.close()
+    with StreamPipeline(window_size, reduced_dim, k_basis, seed, approach, list(modality_types), step_window_ratio,
+                        window_slots=int(os.environ.get("MUSED_WINDOW_SLOTS", "1"))) as pipe:
+        clusters = pipe.run(data_modalities, np.asarray(complete_true_labels))
     results = dict(results or {})
     results["all_clusters"] = clusters
     results["processing_time"] = (time.time_ns() - t0) / 1e9

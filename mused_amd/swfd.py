@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BITS, F32, F64, I64, call
+from ._lib import BITS, F32, F64, I64, MusedError, call
 from .engine import _require_gpu, ptr, stream_ptr
 
 _DT = {torch.float32: F32, torch.float64: F64, torch.int64: I64}
@@ -123,10 +123,20 @@ class SeqBasedSWFD:
         """4-tuple like the reference's get(): (sketch (l, d) float64, singular values of the sketch,
         level used, delta of the final shrink); main.py:70 consumes element 0 only."""
         B, sig, info = self.get_device()
+        self.check()
         info = info.cpu().numpy()
         if self.lanes != 1:
             return B.cpu().numpy(), sig.cpu().numpy(), info[:, 0].astype(int), info[:, 1]
         return B.cpu().numpy(), sig.cpu().numpy(), int(info[0]), float(info[1])
+
+    def check(self):
+        """BLOCKING: raise if an eigensolve of this sketch gave up (its results since then are invalid).  `get()` calls
+        it; callers of the asynchronous `get_device()` call it once the stream has run (the pipeline does in flush())."""
+        st = C.c_int()
+        call("mused_swfd_status", self._h, C.byref(st), stream_ptr())
+        if st.value:
+            raise MusedError(f"SeqBasedSWFD: an eigensolve of a rotation / query gave up (status {st.value}): "
+                             "the sketch is invalid")
 
     # -- live timing of the rotation eigensolver ----------------------------------------------------
     def profile(self, on: bool):
@@ -171,6 +181,10 @@ class SeqBasedSWFD:
             self._h = None
 
     def __del__(self):
+        import sys
+
+        if sys is None or sys.is_finalizing():  # interpreter exit: the HIP runtime may be gone already
+            return
         try:
             self.close()
         except Exception:
