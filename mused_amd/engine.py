@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -430,8 +431,6 @@ class WindowEngine:
             self._rsvd_fb = None
 
     def __del__(self):
-        import sys
-
         if sys is None or sys.is_finalizing():  # interpreter exit: the HIP runtime may already be gone -- leave the
             return                               # handles to the process teardown instead of calling into it
         try:

@@ -349,12 +349,17 @@ class StreamPipeline:
                                for i in range(self._nslots)]
                 self._dpools = [ThreadPoolExecutor(max_workers=1) for _ in range(self._nslots)]
                 # Every engine records its eigenstep graph at its first window.  Do that here, one engine after the other
-                # and before any worker thread exists: a stream capture that overlaps HIP calls of other host threads
-                # (allocations, launches) has failed with "operation failed due to a previous error during capture".
+                # and before any worker thread exists.  What a ThreadLocal capture does not survive on this runtime is a
+                # DEVICE-WIDE synchronisation made by another host thread while it records (tools/repro_capture_threads.hip:
+                # hipDeviceSynchronize beside a capture fails 38 of 40 captures with "operation failed due to a previous
+                # error during capture"; allocations, frees, launches, graph / stream creation and destruction, stream and
+                # event synchronisation beside it: 0 of 40) -- the library therefore serialises its captures with its own
+                # handle creation / destruction (capture_mutex) and nothing here calls torch.cuda.synchronize() off the
+                # caller's thread.
                 for e_, s_ in self._slots:
                     s_.wait_stream(caller)
                     with torch.cuda.stream(s_):
-                        self.window_device(mods, e_)
+                        self.window_device(mods, e_, defer=self._defer)
                     s_.synchronize()
         slot = self._nwin % self._nslots
         eng, st = self._slots[slot]
@@ -430,8 +435,14 @@ class StreamPipeline:
         if self._pool is not None:
             self._kpool.shutdown(wait=True)
             self._pool.shutdown(wait=True)
-        try:
-            torch.cuda.synchronize(self._device)
+        try:  # the streams this pipeline enqueued on (no device-wide synchronisation: another pipeline may be capturing)
+            for _, st in (self._slots or []):
+                if st is not None:
+                    st.synchronize()
+            for st in (self._stream, self._side, self._chk):
+                if st is not None:
+                    st.synchronize()
+            torch.cuda.current_stream().synchronize()
         except Exception as e:  # noqa: BLE001
             err = err or e
         for s in (self.swfd, self.fswfd):

@@ -17,6 +17,7 @@ Host rows are staged and shipped in blocks; the sketch does not depend on the bl
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 import torch
@@ -181,8 +182,6 @@ class SeqBasedSWFD:
             self._h = None
 
     def __del__(self):
-        import sys
-
         if sys is None or sys.is_finalizing():  # interpreter exit: the HIP runtime may be gone already
             return
         try:

@@ -30,7 +30,13 @@ static const char* kNames[] = {"idle (control)",
                                "hipGraphExecDestroy + hipGraphDestroy of a prebuilt graph",
                                "hipMemcpyAsync D2H + hipStreamSynchronize",
                                "hipEventCreate/Record/Synchronize/Destroy",
-                               "hipDeviceSynchronize"};
+                               "hipDeviceSynchronize",
+                               "hipMemset (synchronous, null stream)",
+                               "hipMemcpy host -> device (synchronous)",
+                               "hipMemcpy device -> host (synchronous)",
+                               "hipStreamSynchronize(null stream)",
+                               "hipMemsetAsync on the null stream",
+                               "hipFree of a 64 MB block (hipMalloc before)"};
 constexpr int NKIND = sizeof(kNames) / sizeof(kNames[0]);
 
 struct Prebuilt {
@@ -110,6 +116,12 @@ int main() {
           case 8: e = hipMemcpyAsync(&host, bufB, 4, hipMemcpyDeviceToHost, s); if (e == hipSuccess) e = hipStreamSynchronize(s); break;
           case 9: { hipEvent_t ev; e = hipEventCreate(&ev); if (e == hipSuccess) { hipEventRecord(ev, s); hipEventSynchronize(ev); hipEventDestroy(ev); } break; }
           case 10: e = hipDeviceSynchronize(); break;
+          case 11: e = hipMemset(bufB + 8, 0, 8); break;
+          case 12: e = hipMemcpy(bufB + 8, &host, 4, hipMemcpyHostToDevice); break;
+          case 13: e = hipMemcpy(&host, bufB + 8, 4, hipMemcpyDeviceToHost); break;
+          case 14: e = hipStreamSynchronize(nullptr); break;
+          case 15: e = hipMemsetAsync(bufB + 8, 0, 8, nullptr); break;
+          case 16: { void* p = nullptr; e = hipMalloc(&p, 64u << 20); if (e == hipSuccess) e = hipFree(p); break; }
         }
         if (e != hipSuccess) b_errors.fetch_add(1);
         b_ops.fetch_add(1);
