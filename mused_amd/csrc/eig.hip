@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "wave_ops.h"
 
 namespace mused {
 
@@ -41,6 +42,10 @@ struct EigPlan {
   unsigned* q;        // unit ring: 0 = empty, else 1 + ((matrix * 256 + global round) * 4 + block pair)
   unsigned qcap;
   struct OsjqCtl* qctl;
+  // direct solver for order 256 / top half (trd.hip): runs first, the queue Jacobi then takes the matrices it rejected
+  int trd;
+  double* trd_ws;
+  int* trd_done;       // per matrix: 1 = solved by the direct solver (the Jacobi skips it)
   unsigned long long q_timeout;  // ticks of s_memrealtime (100 MHz) a consumer waits for its ticket (3 s; MUSED_EIG_QUEUE_TIMEOUT_TICKS)
   int* err_out;                  // optional device word the caller reads back: set when the queue solver gave up (results invalid)
   int* qdone;         // per matrix: units of its current round that have finished
@@ -119,32 +124,6 @@ __host__ __device__ constexpr int osj_pair_q(int m2, int step, int k) {
 // value is left a stage halves the count: lanes with the stage bit set keep the upper half of the
 // values, the others the lower half.  On return lane l holds the wave total of value
 // idx = (bits 5, 4, 3, 2[, 1] of l, as many as there were halving stages); lanes sharing idx agree.
-__device__ __forceinline__ double f64_from_parts(unsigned lo, unsigned hi) {
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  // every lane has a valid source under these controls: no "old" value to initialise (mov_dpp, not update_dpp)
-  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
-  return f64_from_parts((unsigned)lo, (unsigned)hi);
-}
-// a <- a(l) + a(l ^ 32) on lanes 0-31, b(l) + b(l ^ 32) on lanes 32-63 (a = kept-by-low, b = kept-by-high)
-__device__ __forceinline__ double swap32_add(double a, double b) {
-  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
-  auto rl = __builtin_amdgcn_permlane32_swap((unsigned)(ua & 0xffffffffull), (unsigned)(ub & 0xffffffffull), false, false);
-  auto rh = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
-  return f64_from_parts(rl[0], rh[0]) + f64_from_parts(rl[1], rh[1]);
-}
-__device__ __forceinline__ double swap16_add(double a, double b) {
-  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
-  auto rl = __builtin_amdgcn_permlane16_swap((unsigned)(ua & 0xffffffffull), (unsigned)(ub & 0xffffffffull), false, false);
-  auto rh = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
-  return f64_from_parts(rl[0], rh[0]) + f64_from_parts(rl[1], rh[1]);
-}
-constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR2 = 0x4E, DPP_QUAD_XOR1 = 0xB1;
-
 template <int N>
 __device__ __forceinline__ double wave_treduce(double (&v)[N], int lane, int& idx) {
   static_assert(N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "wave_treduce: N must be 4, 8, 16, 32 or 64");
@@ -805,7 +784,8 @@ __global__ __launch_bounds__(64 * (OSJ_CB / SC), SC == 8 ? 2 : 1) void osjw_kern
 constexpr unsigned OSJQ_EXIT = 0xffffffffu;
 
 __global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict__ q, int* __restrict__ qdone,
-                                 int* __restrict__ qclean, int batch, int upr, const int* __restrict__ rep) {
+                                 int* __restrict__ qclean, int batch, int upr, const int* __restrict__ rep,
+                                 const int* __restrict__ skip) {
   // (q has been zeroed by the launch before)
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m == 0) {
@@ -815,12 +795,17 @@ __global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict
   qdone[m] = 0;
   qclean[m] = 0;
   if (rep && rep[m] != m) return;
+  if (skip && skip[m]) return;  // already solved by the direct solver
   const unsigned pos = atomicAdd(&ctl->tail, (unsigned)upr);
   for (int i = 0; i < upr; ++i) q[pos + i] = 1u + (((unsigned)m * 256u + 0u) * 4u + (unsigned)i);
   atomicAdd(&ctl->nmat, 1);
 }
 
 __global__ void osjq_reset_kernel(OsjqCtl* __restrict__ ctl) { ctl->tail = 0; ctl->nmat = 0; }
+// nothing was queued (every matrix skipped): the consumers must not wait for tickets that never come
+__global__ void osjq_seal_kernel(OsjqCtl* __restrict__ ctl) {
+  if (ctl->nmat == 0) ctl->all_done = 1;
+}
 
 template <int RP>
 __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, int ldn, int nb, int batch, int max_sweeps,
@@ -923,7 +908,8 @@ static void osjq_launch(EigPlan* p, hipStream_t st) {
   hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap);
   hipLaunchKernelGGL(osjq_reset_kernel, dim3(1), dim3(1), 0, st, p->qctl);
   hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->qclean,
-                     p->batch, upr, p->rep);
+                     p->batch, upr, p->rep, p->trd ? p->trd_done : (const int*)nullptr);
+  if (p->trd) hipLaunchKernelGGL(osjq_seal_kernel, dim3(1), dim3(1), 0, st, p->qctl);
   long units = (long)p->batch * upr;
   const int grid = (int)(units < 512 ? units : 512);  // 2 resident workgroups per CU; fewer than that is fine too
   hipLaunchKernelGGL((osjq_kernel<RP>), dim3(grid), dim3(256), 0, st, p->Gc, p->ldn, nb, p->batch, p->sweeps, p->sort_from,
@@ -1133,7 +1119,13 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
       const char* qe = getenv("MUSED_EIG_QUEUE");
       const int nbq = p->ldn / OSJ_CB;
       const bool fits = p->wavek && p->ldn <= 256 && nbq >= 2 && sweeps * (nbq - 1) <= 255 && batch <= (1 << 21);
-      const bool want = qe ? (qe[0] == '1') : ((long)batch * (nbq / 2) <= 224);
+      bool want = qe ? (qe[0] == '1') : ((long)batch * (nbq / 2) <= 224);
+      {
+        // direct solver (MUSED_EIG_TRD=0 turns it off): order 256 exactly, callers that read the top half only
+        const char* te = getenv("MUSED_EIG_TRD");
+        p->trd = ((flags & EIG_PLAN_TOP_HALF) && n == 256 && p->ldn == 256 && fits && !(te && te[0] == '0')) ? 1 : 0;
+        if (p->trd) want = true;  // its rare rejects go through the one-launch queue solver (nothing queued: it exits at once)
+      }
       p->use_queue = (fits && want) ? 1 : 0;
       if (p->use_queue) {
         p->qcap = (unsigned)((long)batch * (nbq / 2) * (nbq - 1) * sweeps);
@@ -1144,6 +1136,12 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         MUSED_CHECK_HIP(hipMemset(p->qctl, 0, sizeof(OsjqCtl)));
         const char* tq = getenv("MUSED_EIG_QUEUE_TIMEOUT_TICKS");  // test knob: 1 forces the give-up path
         p->q_timeout = tq ? strtoull(tq, nullptr, 10) : 300000000ull;
+      }
+      if (p->trd) {
+        int rc_t = trd_prepare();
+        if (rc_t) return rc_t;
+        MUSED_CHECK_HIP(hipMalloc(&p->trd_ws, sizeof(double) * trd_workspace_doubles(batch)));
+        MUSED_CHECK_HIP(hipMalloc(&p->trd_done, sizeof(int) * (size_t)batch));
       }
     }
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
@@ -1199,6 +1197,8 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->qctl) (void)hipFree(p->qctl);
   if (p->qdone) (void)hipFree(p->qdone);
   if (p->qclean) (void)hipFree(p->qclean);
+  if (p->trd_ws) (void)hipFree(p->trd_ws);
+  if (p->trd_done) (void)hipFree(p->trd_done);
   if (p->ev0) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
@@ -1270,6 +1270,8 @@ bool eig_plan_columns(EigPlan* p, const double** cols, const double** lam, int* 
   return true;
 }
 
+bool eig_plan_direct_solver(EigPlan* p) { return p && p->trd != 0; }
+
 // Input buffer for a caller that writes the matrices itself; when the order needs no padding this is the
 // solver's working copy (no pack pass).
 double* eig_plan_input(EigPlan* p) {
@@ -1291,6 +1293,11 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
                          p->notconv);
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
+    if (p->trd) {
+      if (!p->direct) { set_error("eig_plan_run_inplace: the direct solver needs the caller to fill eig_plan_input"); return MUSED_ERR_STATE; }
+      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st);
+      if (rc) return rc;
+    }
     if (p->have_graph && allow_graph) {
       MUSED_CHECK_HIP(hipGraphLaunch(p->exec, st));
     } else {

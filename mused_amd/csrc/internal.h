@@ -62,6 +62,8 @@ struct EigPlan;
 // captures a larger pipeline that contains this solve).
 constexpr int EIG_PLAN_FIXED_SWEEPS = 1;  // always `sweeps` sweeps (no convergence flags)
 constexpr int EIG_PLAN_NO_SORT = 2;       // no column sorting: column j of the result descends from column j of the input
+constexpr int EIG_PLAN_TOP_HALF = 4;      // the caller reads only the n / 2 largest eigenpairs (FD rotation): order 256 goes to the
+                                          // direct solver (trd.hip), the Jacobi takes what its certificate rejects
 int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr, int flags = 0,
                     int* err_out = nullptr);
 // rep (device, batch ints, optional, read at every solve): matrix b is solved only when rep[b] == b
@@ -73,10 +75,17 @@ void eig_plan_destroy(EigPlan* p);
 int eig_plan_run(EigPlan* p, const double* G, double* evals, double* V, hipStream_t stream);
 int eig_plan_profile(EigPlan* p, bool on);
 int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* bytes_per_launch);
+bool eig_plan_direct_solver(EigPlan* p);  // the plan runs the direct solver (trd.hip) with the Jacobi as its fallback
 double* eig_plan_input(EigPlan* p);  // (batch x n x n) device buffer the caller may fill directly
 // Raw result of the one-sided solver (false: not available): cols[(b * ld + j) * ld + a] = lam_j u_j[a],
 // lam[b * ld + j] = eigenvalue j; valid after eig_plan_run_inplace(p, nullptr, nullptr, ...).
 bool eig_plan_columns(EigPlan* p, const double** cols, const double** lam, int* ld);
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t stream, bool allow_graph);
+
+// trd.hip: direct solver for order 256, top 128 eigenpairs (tridiagonalisation + multisection + twisted factorisation)
+size_t trd_workspace_doubles(int batch);
+int trd_prepare();
+int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d = nullptr,
+              double* dbg_e = nullptr, double* dbg_lam = nullptr, double* dbg_res = nullptr);
 
 }  // namespace mused

@@ -711,7 +711,7 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
   MUSED_CHECK_HIP(hipMemcpy(h->theta, th.data(), 8 * S, hipMemcpyHostToDevice));
   int rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
-  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep, 0, h->status))) return rc;
+  if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep, EIG_PLAN_TOP_HALF, h->status))) return rc;
   if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq, nullptr, 0, h->status))) return rc;
   if (h->n3 < h->n4 && (rc = eig_plan_create(h->n3, lanes, h->sweeps + 2, true, &h->eigq3, nullptr, 0, h->status))) return rc;
   {
@@ -719,7 +719,9 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
     const char* pr = getenv("MUSED_SWFD_PREROT");
     const double *c0 = nullptr, *l0 = nullptr;
     int ld0 = 0;
-    if (!(pr && pr[0] == '0') && eig_plan_columns(h->eig, &c0, &l0, &ld0)) {
+    // (the pre-rotation only saves Jacobi sweeps: with the direct solver it is off unless MUSED_SWFD_PREROT=1 asks for it)
+    const bool want_pre = pr ? (pr[0] != '0') : !eig_plan_direct_solver(h->eig);
+    if (want_pre && eig_plan_columns(h->eig, &c0, &l0, &ld0)) {
       const size_t per_block = (size_t)lanes * ell * dd * 8;
       size_t c = ((size_t)256 << 20) / per_block;
       c = c < 1 ? 1 : (c > (size_t)SWFD_PRE_MAX ? (size_t)SWFD_PRE_MAX : c);

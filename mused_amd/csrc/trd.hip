@@ -1,0 +1,583 @@
+// Direct symmetric eigensolver for the 2l x 2l = 256 x 256 Gram matrix of an FD rotation (the "per-window SVD / rotation
+// step" of SWFD, a6 of SURVEY section 8): ONE workgroup per matrix, the matrix resident in registers, ~2.4 n^3 flop
+// instead of the ~31 n^3 of the one-sided Jacobi (eig.hip), which stays as the fallback and for every other order.
+//
+//   A  Householder tridiagonalisation  G = Q T Q^T          (LAPACK dsytd2, lower variant: 254 reflectors)
+//   B  the 128 largest eigenvalues of T by multisection on Sturm counts (4 lanes per eigenvalue, 5 sub-intervals per pass)
+//   C  their eigenvectors by twisted factorisation of T - lam I (Fernando 1997 / LAPACK dlar1v on T itself): forward and
+//      backward pivot sequences, twist index k = argmin |gamma_k|, z_k = 1 and two two-term recurrences outwards
+//   D  back-transformation  V = Q Z  (reflectors applied in reverse), columns written as lam_j v_j -- the form the
+//      one-sided Jacobi leaves (eig_plan_columns), so the FD `decide` kernel reads either solver's output.
+//
+// Only the top l = 128 eigenpairs are formed: the FD shrink uses lam_0 .. lam_{l-1} (delta = lam_{l-1}) and the vectors of
+// the directions whose shrunk energy survives.  CERTIFICATE instead of trust: a matrix is handed to the Jacobi solver
+// (done[b] = 0, its input left untouched) when any significant vector has a twisted-factorisation residual above 1e-11 |T|,
+// a non-finite norm, a cosine above 1e-8 with one of its 4 neighbours in the spectrum, or when 6 significant eigenvalues lie
+// within 1e-7 lam_0 of each other (eigenvalue clusters: multiple eigenvalues make the vectors of a cluster non-orthogonal).
+//
+// Data layout of phase A (512 threads = a 16 x 32 grid (p, q), 8 waves = 2 x 4, lanes = 8 x 8): thread (p, q) holds the
+// elements (i, j) with i = p + 16 u + 32 a, j = q + 32 b for u < 2, 0 <= b <= a < 8 -- a 2-D cyclic distribution of the
+// lower block triangle, 72 doubles per thread, so the active trailing matrix shrinks evenly over the threads.  The diagonal
+// blocks (a == b) hold BOTH triangles at HALF weight: then  y = A v  is  y_i = sum_j H_ij v_j (row part) + sum_i H_ij v_i
+// (column part) with one uniform expression for every stored element, and the rank-2 update needs no masks either.
+#include <math.h>
+
+#include "internal.h"
+#include "wave_ops.h"
+
+namespace mused {
+
+constexpr int TN = 256, TM = 128, TNT = 512;
+// LDS map (doubles): persistent part, then a scratch region reused by the phases
+constexpr int L_D = 0, L_E = 256, L_DD2 = 512 /* double2[256] = {d_i, e_{i-1}^2} */, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280,
+              L_MISC = 1536 /* 16 scalars + [32][4] exchange */, L_S = 1728;
+constexpr int L_TOTAL = L_S + 16384;  // 17,984 doubles = 143,872 bytes
+// phase A scratch
+constexpr int A_XS = 0 /* [2][256] */, A_RP = 512 /* [4][256] */, A_CP = 1536 /* [2][256] */, A_YS = 2048 /* [256] */, A_RED = 2304;
+// phase C scratch
+constexpr int C_QP = 0 /* [256][32] */, C_QM = 8192;
+// phase D scratch
+constexpr int D_VB = 0 /* [2][256] */, D_SP = 512 /* [2][2][128] */;
+// misc slots
+constexpr int M_GL = 0, M_GU = 1, M_PIV = 2, M_TN = 3;
+
+__host__ __device__ constexpr int tidx(int a, int b) { return a * (a + 1) / 2 + b; }
+
+__device__ __forceinline__ double trd_rcp(double y) {  // reciprocal to rounding: hardware seed (~5e-8) + two Newton steps
+  double r = __builtin_amdgcn_rcp(y);
+  r = fma(fma(-y, r, 1.0), r, r);
+  r = fma(fma(-y, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double trd_rcp1(double y) {  // one Newton step: ~3e-15 relative (Sturm counts: a backward error of
+  double r = __builtin_amdgcn_rcp(y);                   // that size in the off-diagonal entries, below the reduction's own)
+  return fma(fma(-y, r, 1.0), r, r);
+}
+
+// ---- phase A: one Householder step (column k), K = k / 32 selects which register blocks are still active -------------------
+template <int K>
+__device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double* __restrict__ sm, int& cur, const int t,
+                                         const int p, const int q, const int wp, const int wq, double* __restrict__ Hs) {
+  const int kk = k & 31, l = t & 63;
+  double* S = sm + L_S;
+  double* xs = S + A_XS + cur * 256;
+  // (1) column k below the diagonal -> xs (the 16 threads of grid column q == kk hold it)
+  if (q == kk) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int a = K; a < 8; ++a) xs[p + 16 * u + 32 * a] = (a == K ? 2.0 : 1.0) * A[u][tidx(a, K)];
+    if (p == (k & 15)) sm[L_D + k] = 2.0 * ((kk >> 4) ? A[1][tidx(K, K)] : A[0][tidx(K, K)]);
+  }
+  __syncthreads();
+  // (2) Householder vector (dlarfg), every wave on its own: beta = -sign(x0) |x|, tau = (beta - x0) / beta, v = x / (x0 - beta)
+  double sq = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i = l + 64 * m;
+    const double x = xs[i];
+    sq += (i > k + 1) ? x * x : 0.0;
+  }
+  sq = wave_allsum(sq);
+  const double x0 = xs[k + 1];
+  double tau = 0.0, beta = x0, scale = 0.0;
+  if (sq > 0.0) {
+    const double nrm = sqrt(fma(x0, x0, sq));
+    beta = x0 >= 0.0 ? -nrm : nrm;
+    tau = (beta - x0) / beta;
+    scale = 1.0 / (x0 - beta);
+  }
+  if (t == 0) {
+    sm[L_E + k] = beta;
+    sm[L_TAU + k] = tau;
+  }
+  auto v_at = [&](int i) -> double {
+    const double x = xs[i] * scale;
+    return i > k + 1 ? x : (i == k + 1 ? 1.0 : 0.0);
+  };
+  if (t < TN) Hs[(long)k * TN + t] = (tau != 0.0) ? v_at(t) : 0.0;
+  if (tau == 0.0) {  // H = I (uniform over the workgroup: every thread computed the same scalars from the same data)
+    cur ^= 1;
+    return;
+  }
+  // (3) y = A v over the stored elements: row part (sums over q) and column part (sums over p), each followed by its
+  //     in-wave transposing reduction (r over the 8 lanes that differ in lq = lane bits 0-2, c over lp = lane bits 3-5)
+  {
+    double r[16];  // r[2 a + u]: row i = p + 16 (2 a + u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r[e] = 0.0;
+#pragma unroll
+    for (int b = K; b < 8; ++b) {
+      const double vj = v_at(q + 32 * b);
+#pragma unroll
+      for (int a = b; a < 8; ++a) {
+        r[2 * a] = fma(A[0][tidx(a, b)], vj, r[2 * a]);
+        r[2 * a + 1] = fma(A[1][tidx(a, b)], vj, r[2 * a + 1]);
+      }
+    }
+    const bool h2 = (l & 4) != 0, h0 = (l & 1) != 0, h1 = (l & 2) != 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {  // partner 7 - (l & 7) of the 8-lane group: decided by bit 2
+      const double keep = h2 ? r[e + 8] : r[e], send = h2 ? r[e] : r[e + 8];
+      r[e] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // l ^ 1
+      const double keep = h0 ? r[e + 4] : r[e], send = h0 ? r[e] : r[e + 4];
+      r[e] = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // l ^ 2
+      const double keep = h1 ? r[e + 2] : r[e], send = h1 ? r[e] : r[e + 2];
+      r[e] = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send);
+    }
+    const int e0 = (h2 ? 8 : 0) + (h0 ? 4 : 0) + (h1 ? 2 : 0);  // this lane ends with r-values e0, e0 + 1
+    double* rp = S + A_RP + wq * 256;
+    rp[p + 16 * e0] = r[0];
+    rp[p + 16 * (e0 + 1)] = r[1];
+  }
+  {
+    double c[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) c[b] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int a = K; a < 8; ++a) {
+        const double vi = v_at(p + 16 * u + 32 * a);
+#pragma unroll
+        for (int b = K; b <= a; ++b) c[b] = fma(A[u][tidx(a, b)], vi, c[b]);
+      }
+    const bool h5 = (l & 32) != 0, h4 = (l & 16) != 0, h3 = (l & 8) != 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) c[b] = swap32_add(c[b], c[b + 4]);   // lanes 0-31 keep b 0-3, lanes 32-63 keep b 4-7
+#pragma unroll
+    for (int b = 0; b < 2; ++b) c[b] = swap16_add(c[b], c[b + 2]);   // bit 4 clear keeps the lower two, set the upper two
+    {
+      const double keep = h3 ? c[1] : c[0], send = h3 ? c[0] : c[1];
+      c[0] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+    }
+    const int b0 = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
+    (S + A_CP + wp * 256)[q + 32 * b0] = c[0];
+  }
+  __syncthreads();
+  // (5) y_i, and v . y (partials per wave)
+  double* ys = S + A_YS;
+  double* red = S + A_RED;
+  if (t < TN) {
+    const double* rp = S + A_RP;
+    const double* cp = S + A_CP;
+    const double y = ((rp[t] + rp[256 + t]) + (rp[512 + t] + rp[768 + t])) + (cp[t] + cp[256 + t]);
+    ys[t] = y;
+    const double part = wave_allsum(v_at(t) * y);
+    if (l == 0) red[t >> 6] = part;
+  }
+  __syncthreads();
+  const double dot = (red[0] + red[1]) + (red[2] + red[3]);
+  const double alpha = -0.5 * tau * tau * dot;  // w = tau y + alpha v
+  auto w_at = [&](int i, double v) -> double { return i > k ? fma(tau, ys[i], alpha * v) : 0.0; };
+  // (6) A <- A - v w^T - w v^T   (diagonal blocks are held at half weight); one grid-row half (u) at a time: the
+  //     v / w entries of the rows are re-read from LDS instead of being kept across the step (registers)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    double vi[8], wi[8];
+#pragma unroll
+    for (int a = K; a < 8; ++a) {
+      vi[a] = v_at(p + 16 * u + 32 * a);
+      wi[a] = w_at(p + 16 * u + 32 * a, vi[a]);
+    }
+#pragma unroll
+    for (int b = K; b < 8; ++b) {
+      const double vj = v_at(q + 32 * b);
+      const double wj = w_at(q + 32 * b, vj);
+#pragma unroll
+      for (int a = b; a < 8; ++a) {
+        const double f = (a == b) ? 0.5 : 1.0;
+        A[u][tidx(a, b)] = fma(-vi[a], f * wj, fma(-wi[a], f * vj, A[u][tidx(a, b)]));
+      }
+    }
+  }
+  cur ^= 1;
+}
+
+// number of eigenvalues of T below x (negative pivots of the LDL^T of T - x I); dd2[i] = {d_i, e_{i-1}^2}
+__device__ __forceinline__ int trd_sturm(const double2* __restrict__ dd2, double x, double pivmin) {
+  double qv = dd2[0].x - x;
+  if (fabs(qv) < pivmin) qv = -pivmin;
+  int cnt = qv < 0.0 ? 1 : 0;
+#pragma unroll 8
+  for (int i = 1; i < TN; ++i) {
+    const double2 de = dd2[i];
+    qv = fma(-de.y, trd_rcp1(qv), de.x - x);
+    if (fabs(qv) < pivmin) qv = -pivmin;
+    cnt += qv < 0.0 ? 1 : 0;
+  }
+  return cnt;
+}
+
+// ---- phase D: one reflector applied to the 256 x 128 eigenvector block; KD = (k + 1) / 32: rows below 32 KD are untouched -----
+template <int KD>
+__device__ __forceinline__ void trd_apply(double (&Z)[16][4], const double tau, const double* __restrict__ vb,
+                                          double* __restrict__ sp, const int p, const int q, const int wp, const int l,
+                                          double (&vi)[16], double (&s)[4]) {
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) s[cb] = 0.0;
+#pragma unroll
+  for (int a = 2 * KD; a < 16; ++a) {
+    vi[a] = vb[p + 16 * a];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) s[cb] = fma(vi[a], Z[a][cb], s[cb]);
+  }
+  // sum over the 8 lanes that differ in lane bits 3-5 (lp); lane ends with column block 2 * bit5 + bit4
+  s[0] = swap32_add(s[0], s[2]);
+  s[1] = swap32_add(s[1], s[3]);
+  s[0] = swap16_add(s[0], s[1]);
+  s[0] = s[0] + dpp_mov_f64<DPP_ROW_ROR8>(s[0]);
+  if ((l & 8) == 0) sp[wp * 128 + q + 32 * (((l >> 5) & 1) * 2 + ((l >> 4) & 1))] = s[0];
+  (void)tau;
+}
+template <int KD>
+__device__ __forceinline__ void trd_apply2(double (&Z)[16][4], const double tau, const double* __restrict__ sp, const int q,
+                                           const double (&vi)[16]) {
+  double sc[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) sc[cb] = tau * (sp[q + 32 * cb] + sp[128 + q + 32 * cb]);
+#pragma unroll
+  for (int a = 2 * KD; a < 16; ++a)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) Z[a][cb] = fma(-vi[a], sc[cb], Z[a][cb]);
+}
+
+struct TrdDebug {
+  double* d;    // batch x 256
+  double* e;    // batch x 256
+  double* lam;  // batch x 128
+  double* res;  // batch x 128: twisted-factorisation residual / |T|
+};
+
+__global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
+                                                     int* __restrict__ done, double* __restrict__ Hs_all,
+                                                     double* __restrict__ Zg_all, TrdDebug dbg) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int bm = blockIdx.x;
+  if (rep && rep[bm] != bm) {  // duplicate of another matrix / frozen sketch: nothing to solve (the Jacobi skips it too)
+    if (threadIdx.x == 0) done[bm] = 1;
+    return;
+  }
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int wp = w >> 2, wq = w & 3, lp = l >> 3, lq = l & 7;
+  const int p = wp * 8 + lp, q = wq * 8 + lq;
+  double* G = Gc + (long)bm * TN * TN;
+  double* Hs = Hs_all + (long)bm * TN * TN;
+  double* Zg = Zg_all + (long)bm * TN * TM;
+  double* S = sm + L_S;
+
+  // ================= phase A: tridiagonalisation =================
+  {
+    double A[2][36];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          const int i = p + 16 * u + 32 * a, j = q + 32 * b;
+          A[u][tidx(a, b)] = G[(long)j * TN + i] * (a == b ? 0.5 : 1.0);
+        }
+    for (int i = t; i < 512; i += TNT) S[A_XS + i] = 0.0;
+    __syncthreads();
+    int cur = 0;
+#define TRD_RUN(KV)                                                                           \
+    for (int kk_ = 0; kk_ < 32; ++kk_) {                                                      \
+      const int k_ = 32 * (KV) + kk_;                                                         \
+      if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, cur, t, p, q, wp, wq, Hs);                    \
+    }
+    TRD_RUN(0) TRD_RUN(1) TRD_RUN(2) TRD_RUN(3) TRD_RUN(4) TRD_RUN(5) TRD_RUN(6) TRD_RUN(7)
+#undef TRD_RUN
+    if (p == 15 && q == 31) sm[L_D + TN - 1] = 2.0 * A[1][tidx(7, 7)];
+    if (t == 0) { sm[L_E + TN - 1] = 0.0; sm[L_TAU + TN - 1] = 0.0; }
+    __syncthreads();
+  }
+
+  // ================= phase B: the TM largest eigenvalues of T =================
+  double2* dd2 = reinterpret_cast<double2*>(sm + L_DD2);
+  {
+    if (t < TN) {
+      const double em = t > 0 ? sm[L_E + t - 1] : 0.0, ep = sm[L_E + t];
+      dd2[t] = make_double2(sm[L_D + t], em * em);
+      const double rad = fabs(em) + fabs(ep);
+      double lo = sm[L_D + t] - rad, hi = sm[L_D + t] + rad, e2m = ep * ep;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o));
+        hi = fmax(hi, __shfl_xor(hi, o));
+        e2m = fmax(e2m, __shfl_xor(e2m, o));
+      }
+      if (l == 0) { S[3 * w] = lo; S[3 * w + 1] = hi; S[3 * w + 2] = e2m; }
+    }
+    __syncthreads();
+    if (t == 0) {
+      double lo = S[0], hi = S[1], e2m = S[2];
+      for (int ww = 1; ww < 4; ++ww) { lo = fmin(lo, S[3 * ww]); hi = fmax(hi, S[3 * ww + 1]); e2m = fmax(e2m, S[3 * ww + 2]); }
+      const double tn = fmax(fabs(lo), fabs(hi));
+      const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
+      sm[L_MISC + M_GL] = lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv;
+      sm[L_MISC + M_GU] = hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv;
+      sm[L_MISC + M_PIV] = piv;
+      sm[L_MISC + M_TN] = tn;
+    }
+    __syncthreads();
+    const double pivmin = sm[L_MISC + M_PIV];
+    const double gl = sm[L_MISC + M_GL], gu = sm[L_MISC + M_GU];
+    // pass 0: counts at 512 equispaced points locate every eigenvalue to 1 / 513 of the Gershgorin interval
+    int* cnts = reinterpret_cast<int*>(S + 16);
+    const double h0 = (gu - gl) * (1.0 / 513.0);
+    cnts[t] = trd_sturm(dd2, fma(h0, (double)(t + 1), gl), pivmin);
+    __syncthreads();
+    const int r = t >> 2, s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
+    int first = 0;  // smallest point index whose count exceeds jidx (512: none) -- counts are non-decreasing
+    for (int step = 256; step > 0; step >>= 1)
+      if (first + step <= 512 && cnts[first + step - 1] <= jidx) first += step;
+    if (first < 512 && cnts[first] <= jidx) first += 1;
+    double lo = first == 0 ? gl : fma(h0, (double)first, gl);
+    double hi = first >= 512 ? gu : fma(h0, (double)(first + 1), gl);
+    // 19 passes of 5-section by the 4 lanes of a quad: 5^19 > 2^44
+    for (int it = 0; it < 19; ++it) {
+      const double h = (hi - lo) * 0.2;
+      const double x = fma(h, (double)(s + 1), lo);
+      const int above = trd_sturm(dd2, x, pivmin) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
+      int nf = above;
+      nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR1, 0xf, 0xf, false);
+      nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR2, 0xf, 0xf, false);
+      const double nlo = fma(h, (double)nf, lo);
+      hi = (nf == 4) ? hi : fma(h, (double)(nf + 1), lo);
+      lo = nlo;
+    }
+    if (s == 0) sm[L_LAM + r] = 0.5 * (lo + hi);
+    __syncthreads();
+  }
+  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1], tnorm = sm[L_MISC + M_TN];
+  const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
+  auto significant = [&](int c) -> bool { const double lc = sm[L_LAM + c]; return lc > 0.0 && (lc - lamcut) > sigtol; };
+  int* badflag = reinterpret_cast<int*>(sm + L_MISC + 8);
+  if (t == 0) *badflag = 0;
+
+  // ================= phase C: eigenvectors of T by twisted factorisation, 32 at a time =================
+  {
+    const double pivmin = sm[L_MISC + M_PIV];
+    double* qp = S + C_QP;
+    double* qm = S + C_QM;
+    auto guard = [&](double v) -> double { return fabs(v) < pivmin ? -pivmin : v; };
+    double* xch = sm + L_MISC + 16;  // [32][4] exchange between the two lanes of a vector (scratch S is full)
+    for (int rd = 0; rd < TM / 32; ++rd) {
+      __syncthreads();  // the previous round's pivot arrays are free (and *badflag is initialised)
+      // lanes 0 and 8 of every 16: role 0 runs the forward pivots and the part of the vector above the twist index, role 1
+      // the backward pivots and the part below -- two dependent chains of 255 divisions side by side instead of one of 1,020
+      const bool act = (t & 7) == 0;
+      const int role = (t >> 3) & 1, cl = t >> 4, c = rd * 32 + cl;
+      const double lam = sm[L_LAM + c];
+      if (act) {
+        if (role == 0) {
+          double qv = dd2[0].x - lam;
+          qp[cl] = qv;
+          for (int i = 1; i < TN; ++i) {
+            const double2 de = dd2[i];
+            qv = fma(-de.y, trd_rcp(guard(qv)), de.x - lam);
+            qp[i * 32 + cl] = qv;
+          }
+        } else {
+          double qv = dd2[TN - 1].x - lam;
+          qm[(TN - 1) * 32 + cl] = qv;
+          for (int i = TN - 2; i >= 0; --i) {
+            qv = fma(-dd2[i + 1].y, trd_rcp(guard(qv)), dd2[i].x - lam);
+            qm[i * 32 + cl] = qv;
+          }
+        }
+      }
+      __syncthreads();
+      if (act) {  // gamma_i = qp_i + qm_i - (d_i - lam): each role scans one half, ties to the smaller index
+        const int i0 = role * (TN / 2);
+        double best = 1.7976931348623157e308;
+        int kt = i0;
+        for (int i = i0; i < i0 + TN / 2; ++i) {
+          const double g = fabs((qp[i * 32 + cl] + qm[i * 32 + cl]) - (dd2[i].x - lam));
+          if (g < best) { best = g; kt = i; }
+        }
+        xch[cl * 4 + role] = best;
+        xch[cl * 4 + 2 + role] = (double)kt;
+      }
+      __syncthreads();
+      int kt = 0;
+      double gbest = 0.0;
+      if (act) {
+        const double b0 = xch[cl * 4], b1 = xch[cl * 4 + 1];
+        const bool up = !(b1 < b0);  // ties: the smaller index (first half)
+        gbest = up ? b0 : b1;
+        kt = (int)(up ? xch[cl * 4 + 2] : xch[cl * 4 + 3]);
+      }
+      __syncthreads();  // xch is read: it may be rewritten
+      if (act) {
+        double ss = 0.0, zc = 1.0;
+        if (role == 0) {
+          Zg[(long)kt * TM + c] = 1.0;
+          for (int i = kt - 1; i >= 0; --i) {
+            zc = -sm[L_E + i] * zc * trd_rcp(guard(qp[i * 32 + cl]));
+            Zg[(long)i * TM + c] = zc;
+            ss = fma(zc, zc, ss);
+          }
+        } else {
+          for (int i = kt + 1; i < TN; ++i) {
+            zc = -sm[L_E + i - 1] * zc * trd_rcp(guard(qm[i * 32 + cl]));
+            Zg[(long)i * TM + c] = zc;
+            ss = fma(zc, zc, ss);
+          }
+        }
+        xch[cl * 4 + role] = ss;
+      }
+      __syncthreads();
+      if (act && role == 0) {
+        const double ss = 1.0 + xch[cl * 4] + xch[cl * 4 + 1];
+        const double zs = 1.0 / sqrt(ss);
+        sm[L_ZS + c] = zs;
+        const double res = gbest * zs / (tnorm > 0.0 ? tnorm : 1.0);
+        if (dbg.res) dbg.res[(long)bm * TM + c] = res;
+        if (significant(c) && !(ss < 1e300 && res <= 1e-11)) atomicOr(badflag, 1);
+      }
+    }
+    __syncthreads();
+    // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
+    {
+      const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
+      if (c2 < TM && significant(c) && significant(c2)) {
+        double dotv = 0.0;
+        for (int i = 0; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
+        if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= 1e-8)) atomicOr(badflag, 2);
+      }
+      if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5) &&
+          (sm[L_LAM + c] - sm[L_LAM + c + 5]) <= 1e-7 * lam0)
+        atomicOr(badflag, 4);
+    }
+    __syncthreads();
+  }
+  if (dbg.d) {
+    if (t < TN) { dbg.d[(long)bm * TN + t] = sm[L_D + t]; dbg.e[(long)bm * TN + t] = sm[L_E + t]; }
+    if (t < TM) dbg.lam[(long)bm * TM + t] = sm[L_LAM + t];
+  }
+  if (*badflag) {  // leave G as it is: the Jacobi solver takes this matrix
+    if (t == 0) done[bm] = 0;
+    return;
+  }
+
+  // ================= phase D: V = Q Z, columns written as lam_j v_j =================
+  {
+    double Z[16][4];
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) Z[a][cb] = Zg[(long)(p + 16 * a) * TM + q + 32 * cb] * sm[L_ZS + q + 32 * cb];
+    __syncthreads();  // scratch region: pivot arrays -> reflector / partial-sum buffers
+    double* vbuf = S + D_VB;
+    double* spb = S + D_SP;
+    if (t < TN) vbuf[t] = Hs[(long)(TN - 3) * TN + t];
+    __syncthreads();
+    int par = 0;
+    for (int k = TN - 3; k >= 0; --k) {
+      const double vnext = (t < TN && k > 0) ? Hs[(long)(k - 1) * TN + t] : 0.0;
+      const double tau = sm[L_TAU + k];
+      double vi[16], s4[4];
+      const double* vb = vbuf + par * 256;
+      double* sp = spb + par * 256;
+      if (tau != 0.0) {
+        switch ((k + 1) >> 5) {
+          case 0: trd_apply<0>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          case 1: trd_apply<1>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          case 2: trd_apply<2>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          case 3: trd_apply<3>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          case 4: trd_apply<4>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          case 5: trd_apply<5>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          case 6: trd_apply<6>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+          default: trd_apply<7>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+        }
+      }
+      if (t < TN) vbuf[(par ^ 1) * 256 + t] = vnext;
+      __syncthreads();
+      if (tau != 0.0) {
+        switch ((k + 1) >> 5) {
+          case 0: trd_apply2<0>(Z, tau, sp, q, vi); break;
+          case 1: trd_apply2<1>(Z, tau, sp, q, vi); break;
+          case 2: trd_apply2<2>(Z, tau, sp, q, vi); break;
+          case 3: trd_apply2<3>(Z, tau, sp, q, vi); break;
+          case 4: trd_apply2<4>(Z, tau, sp, q, vi); break;
+          case 5: trd_apply2<5>(Z, tau, sp, q, vi); break;
+          case 6: trd_apply2<6>(Z, tau, sp, q, vi); break;
+          default: trd_apply2<7>(Z, tau, sp, q, vi); break;
+        }
+      }
+      par ^= 1;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int c = q + 32 * cb;
+      const double lc = sm[L_LAM + c];
+      const double f = lc > 0.0 ? lc : 0.0;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        G[(long)c * TN + p + 16 * a] = f * Z[a][cb];
+        G[(long)(c + TM) * TN + p + 16 * a] = 0.0;
+      }
+    }
+    if (t == 0) done[bm] = 1;
+  }
+}
+
+}  // namespace mused
+
+namespace mused {
+
+// Workspace per matrix: reflectors (256 x 256) + tridiagonal eigenvectors (256 x 128), doubles
+size_t trd_workspace_doubles(int batch) { return (size_t)batch * ((size_t)TN * TN + (size_t)TN * TM); }
+
+int trd_prepare() {
+  static std::once_flag once;
+  static hipError_t rc = hipSuccess;
+  std::call_once(once, [] {
+    rc = hipFuncSetAttribute((const void*)trd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_TOTAL));
+  });
+  MUSED_CHECK_HIP(rc);
+  return MUSED_OK;
+}
+
+// Solves the matrices of Gc (batch x 256 x 256, symmetric) in place: done[b] = 1 -> columns 0 .. 127 of matrix b hold
+// lam_j v_j for its 128 largest eigenvalues (descending), columns 128 .. 255 zeros; done[b] = 0 -> untouched (certificate
+// failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.
+int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d, double* dbg_e,
+              double* dbg_lam, double* dbg_res) {
+  TrdDebug dbg{dbg_d, dbg_e, dbg_lam, dbg_res};
+  double* Hs = ws;
+  double* Zg = ws + (size_t)batch * TN * TN;
+  hipLaunchKernelGGL(trd_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_TOTAL, st, Gc, rep, done, Hs, Zg, dbg);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
+}  // namespace mused
+
+using namespace mused;
+
+// Diagnostic / unit-test entry (not part of the declared ABI): runs the direct solver alone on `batch` symmetric 256 x 256
+// matrices (device, overwritten as trd_solve does) and returns the intermediate quantities of every phase.
+// out_d / out_e: batch x 256 (tridiagonal), out_lam: batch x 128 (descending), out_res: batch x 128, out_done: batch ints.
+extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_e, double* out_lam, double* out_res,
+                               int* out_done, void* stream) {
+  MUSED_REQUIRE(G && batch >= 1 && out_done, "mused_debug_trd: bad arguments");
+  int rc = trd_prepare();
+  if (rc) return rc;
+  double* ws = nullptr;
+  MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trd_workspace_doubles(batch)));
+  rc = trd_solve(G, batch, nullptr, out_done, ws, (hipStream_t)stream, out_d, out_e, out_lam, out_res);
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(ws);
+  if (rc) return rc;
+  MUSED_CHECK_HIP(e);
+  return MUSED_OK;
+}

@@ -1,0 +1,158 @@
+"""The direct eigensolver of the FD rotation (csrc/trd.hip: tridiagonalisation + multisection + twisted factorisation +
+back-transformation, order 256, top 128 eigenpairs) phase by phase against NumPy / LAPACK, and its certificate."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def sytd2_lower(G):
+    """LAPACK dsytd2 (uplo = 'L'), unblocked: d, e of T = Q^T G Q."""
+    A = np.array(G, dtype=np.float64)
+    n = A.shape[0]
+    d, e = np.zeros(n), np.zeros(n)
+    for k in range(n - 1):
+        x = A[k + 1:, k].copy()
+        alpha, xnorm = x[0], np.linalg.norm(x[1:])
+        d[k] = A[k, k]
+        if xnorm == 0.0:
+            e[k] = alpha
+            continue
+        beta = -np.copysign(np.hypot(alpha, xnorm), alpha)
+        tau = (beta - alpha) / beta
+        v = x / (alpha - beta)
+        v[0] = 1.0
+        e[k] = beta
+        p = tau * (A[k + 1:, k + 1:] @ v)
+        w = p - 0.5 * tau * (p @ v) * v
+        A[k + 1:, k + 1:] -= np.outer(v, w) + np.outer(w, v)
+    d[n - 1] = A[n - 1, n - 1]
+    return d, e
+
+
+def run_trd(Gs):
+    from mused_amd import _lib
+    from mused_amd.engine import ptr, stream_ptr
+
+    L = _lib.lib()
+    fn = L.mused_debug_trd
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 1 + [C.c_int] + [C.c_void_p] * 6
+    B = len(Gs)
+    G = torch.from_numpy(np.ascontiguousarray(np.stack(Gs))).cuda()
+    d = torch.zeros(B, 256, dtype=torch.float64, device="cuda")
+    e = torch.zeros(B, 256, dtype=torch.float64, device="cuda")
+    lam = torch.zeros(B, 128, dtype=torch.float64, device="cuda")
+    res = torch.zeros(B, 128, dtype=torch.float64, device="cuda")
+    done = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(fn(ptr(G), B, ptr(d), ptr(e), ptr(lam), ptr(res), ptr(done), stream_ptr()))
+    torch.cuda.synchronize()
+    return G.cpu().numpy(), d.cpu().numpy(), e.cpu().numpy(), lam.cpu().numpy(), res.cpu().numpy(), done.cpu().numpy()
+
+
+def fd_buffers(kind, nblk, seed=0, ell=128, d=1024):
+    """Gram matrices of successive FD rotation buffers [kept rows; new block; zero rows] of a synthetic stream."""
+    from mused_amd import synth
+
+    X, _ = synth.stream_window(kind, 0, ell * nblk, d, seed)
+    X = X.astype(np.float64)
+    K = np.zeros((0, d))
+    out = []
+    for blk in range(nblk):
+        buf = np.vstack([K, X[blk * ell:(blk + 1) * ell]])
+        buf = np.vstack([buf, np.zeros((2 * ell - len(buf), d))])
+        out.append(buf @ buf.T)
+        _, s, Vt = np.linalg.svd(buf, full_matrices=False)
+        lam = s ** 2
+        s2 = np.maximum(lam[:ell] - lam[ell - 1], 0)
+        keep = s2 > 1e-10 * lam[0]
+        K = np.sqrt(s2[keep])[:, None] * Vt[:ell][keep]
+    return out
+
+
+@pytest.mark.parametrize("kind", ["blob", "gauss", "fd"])
+def test_direct_solver_on_fd_rotation_buffers(kind):
+    Gs = fd_buffers(kind, 5)
+    out, d, e, lam, res, done = run_trd(Gs)
+    for b, G in enumerate(Gs):
+        scale = np.abs(np.linalg.eigvalsh(G)).max()
+        dr, er = sytd2_lower(G)
+        np.testing.assert_allclose(d[b], dr, rtol=0, atol=2e-12 * scale)       # phase A
+        np.testing.assert_allclose(e[b, :255], er[:255], rtol=0, atol=2e-12 * scale)
+        w = np.linalg.eigvalsh(G)[::-1]
+        np.testing.assert_allclose(lam[b], w[:128], rtol=0, atol=1e-13 * scale)  # phase B
+        assert done[b] == 1, (b, res[b].max())
+        cols = out[b][:128].T   # out[b][c] = column c (column-major storage) -> (256, 128)
+        nrm = np.linalg.norm(cols, axis=0)
+        np.testing.assert_allclose(nrm, np.maximum(w[:128], 0), rtol=0, atol=1e-12 * scale)  # |lam_j v_j| = lam_j
+        sig = (w[:128] - w[127]) > 1e-10 * w[0]
+        V = cols[:, sig] / nrm[sig]
+        assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-9                # orthonormal
+        R = G @ V - V * w[:128][sig]
+        assert np.abs(R).max() < 1e-11 * scale                                  # eigenvectors of G
+        assert not out[b][128:].any()                                           # the lower half of the spectrum: zero columns
+
+
+def test_direct_solver_special_matrices_and_certificate():
+    rng = np.random.default_rng(1)
+    Q = np.linalg.qr(rng.standard_normal((256, 256)))[0]
+    cases = {
+        "zero": np.zeros((256, 256)),
+        "identity": np.eye(256) * 3.0,                                           # 256-fold eigenvalue, but nothing survives the shrink
+        "hundredfold": (Q * np.r_[np.full(100, 5.0), np.linspace(4, 1, 156)]) @ Q.T,  # 100-fold eigenvalue -> rejected
+        "rank40": (lambda B: B @ B.T)(rng.standard_normal((256, 40))),
+        "diagonal": np.diag(np.linspace(1, 300, 256)),
+        "graded": (Q * np.logspace(0, -12, 256)) @ Q.T,
+        "binary": (lambda A: A @ A.T)((rng.random((256, 2000)) < 0.025).astype(float)),
+    }
+    names = list(cases)
+    Gs = [0.5 * (cases[k] + cases[k].T) for k in names]
+    out, d, e, lam, res, done = run_trd(Gs)
+    for b, name in enumerate(names):
+        G = Gs[b]
+        w = np.linalg.eigvalsh(G)[::-1]
+        scale = max(np.abs(w).max(), 1e-300)
+        np.testing.assert_allclose(lam[b], w[:128], rtol=0, atol=1e-13 * scale, err_msg=name)
+        if name == "hundredfold":
+            assert done[b] == 0, name                      # certificate: clustered eigenvalues go to the Jacobi solver
+            assert np.array_equal(out[b], G), name         # ... with their input untouched
+            continue
+        assert done[b] == 1, (name, res[b].max())
+        cols = out[b][:128].T
+        nrm = np.linalg.norm(cols, axis=0)
+        np.testing.assert_allclose(nrm, np.maximum(w[:128], 0), rtol=0, atol=1e-12 * scale, err_msg=name)
+        sig = (w[:128] > 0) & ((w[:128] - w[127]) > 1e-10 * max(w[0], 0))
+        if sig.any():
+            V = cols[:, sig] / nrm[sig]
+            assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-8, name
+            assert np.abs(G @ V - V * w[:128][sig]).max() < 1e-10 * scale, name
+
+
+def test_fd_rotation_through_the_plan_matches_svd():
+    """mused_fd_rotate (one rotation of a 256 x d buffer, l = 128: the plan now runs the direct solver) against the SVD."""
+    from mused_amd import _lib
+    from mused_amd.engine import ptr, stream_ptr
+
+    rng = np.random.default_rng(3)
+    ell, dd = 128, 700
+    buf = rng.standard_normal((2 * ell, dd)) * np.logspace(0, -3, 2 * ell)[:, None]
+    _, s, Vt = np.linalg.svd(buf, full_matrices=False)
+    lam = s ** 2
+    ref = np.sqrt(np.maximum(lam[:ell] - lam[ell - 1], 0))
+    t = torch.from_numpy(buf).cuda()
+    sig = torch.zeros(ell, dtype=torch.float64, device="cuda")
+    _lib.call("mused_fd_rotate", ptr(t), ell, dd, ptr(sig), 0, stream_ptr())
+    got = np.sort(sig.cpu().numpy())[::-1]
+    keep = ref ** 2 > 1e-10 * lam[0]
+    np.testing.assert_allclose(got[: keep.sum()], ref[keep], rtol=0, atol=1e-9 * s[0])
+    B = t.cpu().numpy()[:ell]
+    np.testing.assert_allclose(B.T @ B, (Vt[:ell].T * np.where(keep, ref ** 2, 0)) @ Vt[:ell], rtol=0, atol=1e-9 * lam[0])
