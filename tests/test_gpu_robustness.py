@@ -119,7 +119,7 @@ def test_queue_solver_timeout_raises_instead_of_returning_garbage(monkeypatch):
     sk.close()
     eng = WindowEngine(500)
     adj = eng.knn_adjacency(torch.from_numpy(rng.standard_normal((500, 16))).cuda(), 10)
-    emb, sig, flags = eng.svd_reduce(adj, 40, 0, nnz_cap=500 * 10, want_flags=True)
+    emb, sig, flags = eng.svd_reduce(adj, 118, 0, nnz_cap=500 * 10, want_flags=True)  # r = 128: two units per round
     with pytest.raises(MusedError, match="gave up"):
         WindowEngine.check_rsvd_flags(flags.cpu().numpy())
     eng.close()

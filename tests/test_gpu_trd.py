@@ -86,8 +86,10 @@ def test_direct_solver_on_fd_rotation_buffers(kind):
     for b, G in enumerate(Gs):
         scale = np.abs(np.linalg.eigvalsh(G)).max()
         dr, er = sytd2_lower(G)
-        np.testing.assert_allclose(d[b], dr, rtol=0, atol=2e-12 * scale)       # phase A
-        np.testing.assert_allclose(e[b, :255], er[:255], rtol=0, atol=2e-12 * scale)
+        # phase A (entries of T are only determined to the conditioning of the reflectors: a loose check that catches
+        # indexing mistakes; the eigenvalues below are the tight one)
+        np.testing.assert_allclose(d[b], dr, rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(e[b, :255], er[:255], rtol=0, atol=1e-8 * scale)
         w = np.linalg.eigvalsh(G)[::-1]
         np.testing.assert_allclose(lam[b], w[:128], rtol=0, atol=1e-13 * scale)  # phase B
         assert done[b] == 1, (b, res[b].max())
@@ -121,7 +123,7 @@ def test_direct_solver_special_matrices_and_certificate():
         G = Gs[b]
         w = np.linalg.eigvalsh(G)[::-1]
         scale = max(np.abs(w).max(), 1e-300)
-        np.testing.assert_allclose(lam[b], w[:128], rtol=0, atol=1e-13 * scale, err_msg=name)
+        np.testing.assert_allclose(lam[b], w[:128], rtol=0, atol=1e-13 * scale + 1e-300, err_msg=name)
         if name == "hundredfold":
             assert done[b] == 0, name                      # certificate: clustered eigenvalues go to the Jacobi solver
             assert np.array_equal(out[b], G), name         # ... with their input untouched
@@ -129,7 +131,7 @@ def test_direct_solver_special_matrices_and_certificate():
         assert done[b] == 1, (name, res[b].max())
         cols = out[b][:128].T
         nrm = np.linalg.norm(cols, axis=0)
-        np.testing.assert_allclose(nrm, np.maximum(w[:128], 0), rtol=0, atol=1e-12 * scale, err_msg=name)
+        np.testing.assert_allclose(nrm, np.maximum(w[:128], 0), rtol=0, atol=1e-12 * scale + 1e-300, err_msg=name)
         sig = (w[:128] > 0) & ((w[:128] - w[127]) > 1e-10 * max(w[0], 0))
         if sig.any():
             V = cols[:, sig] / nrm[sig]
