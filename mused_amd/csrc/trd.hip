@@ -581,3 +581,38 @@ extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_
   MUSED_CHECK_HIP(e);
   return MUSED_OK;
 }
+
+// Diagnostic: average time (ms, HIP events) of `reps` direct solves of the same `batch` matrices (G is restored from a
+// copy before every solve; the copy is outside the timed region).
+extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double* out_ms, int* out_done, void* stream) {
+  MUSED_REQUIRE(G && batch >= 1 && reps >= 1 && out_ms, "mused_debug_trd_time: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = trd_prepare();
+  if (rc) return rc;
+  double *ws = nullptr, *work = nullptr;
+  int* done = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)batch * TN * TN;
+  MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trd_workspace_doubles(batch)));
+  MUSED_CHECK_HIP(hipMalloc((void**)&work, bytes));
+  MUSED_CHECK_HIP(hipMalloc((void**)&done, sizeof(int) * (size_t)batch));
+  hipEvent_t e0, e1;
+  MUSED_CHECK_HIP(hipEventCreate(&e0));
+  MUSED_CHECK_HIP(hipEventCreate(&e1));
+  double total = 0.0;
+  for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
+    MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
+    MUSED_CHECK_HIP(hipEventRecord(e0, st));
+    rc = trd_solve(work, batch, nullptr, done, ws, st);
+    MUSED_CHECK_HIP(hipEventRecord(e1, st));
+    MUSED_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MUSED_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (i > 0) total += ms;
+  }
+  *out_ms = total / reps;
+  if (out_done) MUSED_CHECK_HIP(hipMemcpy(out_done, done, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(ws); (void)hipFree(work); (void)hipFree(done);
+  return rc;
+}
