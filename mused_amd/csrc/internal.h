@@ -86,6 +86,6 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t strea
 size_t trd_workspace_doubles(int batch);
 int trd_prepare();
 int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d = nullptr,
-              double* dbg_e = nullptr, double* dbg_lam = nullptr, double* dbg_res = nullptr);
+              double* dbg_e = nullptr, double* dbg_lam = nullptr, double* dbg_res = nullptr, long long* dbg_clk = nullptr);
 
 }  // namespace mused

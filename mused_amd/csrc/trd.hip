@@ -33,11 +33,11 @@ constexpr int L_D = 0, L_E = 256, L_DD2 = 512 /* double2[256] = {d_i, e_{i-1}^2}
               L_MISC = 1536 /* 16 scalars + [32][4] exchange */, L_S = 1728;
 constexpr int L_TOTAL = L_S + 16384;  // 17,984 doubles = 143,872 bytes
 // phase A scratch
-constexpr int A_XS = 0 /* [2][256] */, A_RP = 512 /* [4][256] */, A_CP = 1536 /* [2][256] */, A_YS = 2048 /* [256] */, A_RED = 2304;
+constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][256] */, A_CP = 1792 /* [2][256] */, A_RED = 2304 /* [8] */;
 // phase C scratch
 constexpr int C_QP = 0 /* [256][32] */, C_QM = 8192;
 // phase D scratch
-constexpr int D_VB = 0 /* [2][256] */, D_SP = 512 /* [2][2][128] */;
+constexpr int D_VB = 0 /* [2][16][256] */, D_SP = 8192 /* [2][2][128] */;
 // misc slots
 constexpr int M_GL = 0, M_GU = 1, M_PIV = 2, M_TN = 3;
 
@@ -55,12 +55,17 @@ __device__ __forceinline__ double trd_rcp1(double y) {  // one Newton step: ~3e-
 }
 
 // ---- phase A: one Householder step (column k), K = k / 32 selects which register blocks are still active -------------------
+// Four workgroup barriers per step: column k -> LDS | Householder vector v -> LDS | partial sums of y = A v (and of v . y)
+// -> LDS | w -> LDS.  v and w are stored as plain vectors (zeros where the reflector does not act), so that the 2 x 36
+// register elements of a thread are updated from unconditional LDS reads.
 template <int K>
-__device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double* __restrict__ sm, int& cur, const int t,
-                                         const int p, const int q, const int wp, const int wq, double* __restrict__ Hs) {
+__device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double* __restrict__ sm, const int t, const int p,
+                                         const int q, const int wp, const int wq, double* __restrict__ Hs) {
   const int kk = k & 31, l = t & 63;
   double* S = sm + L_S;
-  double* xs = S + A_XS + cur * 256;
+  double* xs = S + A_XS;
+  double* vs = S + A_VS;
+  double* ws = S + A_WS;
   // (1) column k below the diagonal -> xs (the 16 threads of grid column q == kk hold it)
   if (q == kk) {
 #pragma unroll
@@ -82,39 +87,55 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
   const double x0 = xs[k + 1];
   double tau = 0.0, beta = x0, scale = 0.0;
   if (sq > 0.0) {
-    const double nrm = sqrt(fma(x0, x0, sq));
+    const double h = fma(x0, x0, sq);
+    double rs = __builtin_amdgcn_rsq(h);  // 1 / sqrt(h): seed + two Newton steps
+    rs = rs * fma(-0.5 * h, rs * rs, 1.5);
+    rs = rs * fma(-0.5 * h, rs * rs, 1.5);
+    const double nrm = h * rs;
     beta = x0 >= 0.0 ? -nrm : nrm;
-    tau = (beta - x0) / beta;
-    scale = 1.0 / (x0 - beta);
+    tau = (beta - x0) * trd_rcp(beta);
+    scale = trd_rcp(x0 - beta);
   }
-  if (t == 0) {
-    sm[L_E + k] = beta;
-    sm[L_TAU + k] = tau;
+  if (t < TN) {
+    const double v = (tau != 0.0) ? (t > k + 1 ? xs[t] * scale : (t == k + 1 ? 1.0 : 0.0)) : 0.0;
+    vs[t] = v;
+    Hs[(long)k * TN + t] = v;
+    if (t == 0) {
+      sm[L_E + k] = beta;
+      sm[L_TAU + k] = tau;
+    }
   }
-  auto v_at = [&](int i) -> double {
-    const double x = xs[i] * scale;
-    return i > k + 1 ? x : (i == k + 1 ? 1.0 : 0.0);
-  };
-  if (t < TN) Hs[(long)k * TN + t] = (tau != 0.0) ? v_at(t) : 0.0;
-  if (tau == 0.0) {  // H = I (uniform over the workgroup: every thread computed the same scalars from the same data)
-    cur ^= 1;
-    return;
-  }
-  // (3) y = A v over the stored elements: row part (sums over q) and column part (sums over p), each followed by its
-  //     in-wave transposing reduction (r over the 8 lanes that differ in lq = lane bits 0-2, c over lp = lane bits 3-5)
+  __syncthreads();
+  if (tau == 0.0) return;  // H = I (uniform over the workgroup: every thread computed the same scalars from the same data)
+  // (3) y = A v over the stored elements: row part r (to be summed over q) and column part c (to be summed over p).
+  //     v . y = v^T A v = 2 sum over the stored elements of H_ij v_i v_j = 2 sum_threads sum_rows v_i r_i: no second pass.
   {
     double r[16];  // r[2 a + u]: row i = p + 16 (2 a + u)
 #pragma unroll
     for (int e = 0; e < 16; ++e) r[e] = 0.0;
 #pragma unroll
     for (int b = K; b < 8; ++b) {
-      const double vj = v_at(q + 32 * b);
+      const double vj = vs[q + 32 * b];
 #pragma unroll
       for (int a = b; a < 8; ++a) {
         r[2 * a] = fma(A[0][tidx(a, b)], vj, r[2 * a]);
         r[2 * a + 1] = fma(A[1][tidx(a, b)], vj, r[2 * a + 1]);
       }
     }
+    double c[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) c[b] = 0.0;
+    double dpart = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int a = K; a < 8; ++a) {
+        const double vi = vs[p + 16 * u + 32 * a];
+        dpart = fma(vi, r[2 * a + u], dpart);
+#pragma unroll
+        for (int b = K; b <= a; ++b) c[b] = fma(A[u][tidx(a, b)], vi, c[b]);
+      }
+    // (4) in-wave transposing reductions: r over the 8 lanes that differ in lq (lane bits 0-2), c over lp (lane bits 3-5)
     const bool h2 = (l & 4) != 0, h0 = (l & 1) != 0, h1 = (l & 2) != 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {  // partner 7 - (l & 7) of the 8-lane group: decided by bit 2
@@ -135,19 +156,6 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
     double* rp = S + A_RP + wq * 256;
     rp[p + 16 * e0] = r[0];
     rp[p + 16 * (e0 + 1)] = r[1];
-  }
-  {
-    double c[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) c[b] = 0.0;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int a = K; a < 8; ++a) {
-        const double vi = v_at(p + 16 * u + 32 * a);
-#pragma unroll
-        for (int b = K; b <= a; ++b) c[b] = fma(A[u][tidx(a, b)], vi, c[b]);
-      }
     const bool h5 = (l & 32) != 0, h4 = (l & 16) != 0, h3 = (l & 8) != 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) c[b] = swap32_add(c[b], c[b + 4]);   // lanes 0-31 keep b 0-3, lanes 32-63 keep b 4-7
@@ -159,45 +167,39 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
     }
     const int b0 = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
     (S + A_CP + wp * 256)[q + 32 * b0] = c[0];
+    dpart = wave_allsum(dpart);
+    if (l == 0) S[A_RED + (t >> 6)] = dpart;
   }
   __syncthreads();
-  // (5) y_i, and v . y (partials per wave)
-  double* ys = S + A_YS;
-  double* red = S + A_RED;
+  // (5) y_i -> w_i = tau y_i - (tau^2 / 2) (v . y) v_i
   if (t < TN) {
     const double* rp = S + A_RP;
     const double* cp = S + A_CP;
+    const double* red = S + A_RED;
     const double y = ((rp[t] + rp[256 + t]) + (rp[512 + t] + rp[768 + t])) + (cp[t] + cp[256 + t]);
-    ys[t] = y;
-    const double part = wave_allsum(v_at(t) * y);
-    if (l == 0) red[t >> 6] = part;
+    const double dot = 2.0 * (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
+    const double alpha = -0.5 * tau * tau * dot;
+    ws[t] = t > k ? fma(tau, y, alpha * vs[t]) : 0.0;
   }
   __syncthreads();
-  const double dot = (red[0] + red[1]) + (red[2] + red[3]);
-  const double alpha = -0.5 * tau * tau * dot;  // w = tau y + alpha v
-  auto w_at = [&](int i, double v) -> double { return i > k ? fma(tau, ys[i], alpha * v) : 0.0; };
-  // (6) A <- A - v w^T - w v^T   (diagonal blocks are held at half weight); one grid-row half (u) at a time: the
-  //     v / w entries of the rows are re-read from LDS instead of being kept across the step (registers)
+  // (6) A <- A - v w^T - w v^T   (diagonal blocks are held at half weight); one grid-row half (u) at a time
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     double vi[8], wi[8];
 #pragma unroll
     for (int a = K; a < 8; ++a) {
-      vi[a] = v_at(p + 16 * u + 32 * a);
-      wi[a] = w_at(p + 16 * u + 32 * a, vi[a]);
+      vi[a] = vs[p + 16 * u + 32 * a];
+      wi[a] = ws[p + 16 * u + 32 * a];
     }
 #pragma unroll
     for (int b = K; b < 8; ++b) {
-      const double vj = v_at(q + 32 * b);
-      const double wj = w_at(q + 32 * b, vj);
+      const double vj = vs[q + 32 * b], wj = ws[q + 32 * b];
+      const double vjh = 0.5 * vj, wjh = 0.5 * wj;
 #pragma unroll
-      for (int a = b; a < 8; ++a) {
-        const double f = (a == b) ? 0.5 : 1.0;
-        A[u][tidx(a, b)] = fma(-vi[a], f * wj, fma(-wi[a], f * vj, A[u][tidx(a, b)]));
-      }
+      for (int a = b; a < 8; ++a)
+        A[u][tidx(a, b)] = fma(-vi[a], (a == b) ? wjh : wj, fma(-wi[a], (a == b) ? vjh : vj, A[u][tidx(a, b)]));
     }
   }
-  cur ^= 1;
 }
 
 // number of eigenvalues of T below x (negative pivots of the LDL^T of T - x I); dd2[i] = {d_i, e_{i-1}^2}
@@ -253,6 +255,7 @@ struct TrdDebug {
   double* e;    // batch x 256
   double* lam;  // batch x 128
   double* res;  // batch x 128: twisted-factorisation residual / |T|
+  long long* clk;  // batch x 8: wall_clock64() (100 MHz) at the phase boundaries
 };
 
 __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
   double* Zg = Zg_all + (long)bm * TN * TM;
   double* S = sm + L_S;
 
+  auto stamp = [&](int i) { if (dbg.clk && t == 0) dbg.clk[(long)bm * 8 + i] = wall_clock64(); };
+  stamp(0);
   // ================= phase A: tridiagonalisation =================
   {
     double A[2][36];
@@ -284,13 +289,12 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
           const int i = p + 16 * u + 32 * a, j = q + 32 * b;
           A[u][tidx(a, b)] = G[(long)j * TN + i] * (a == b ? 0.5 : 1.0);
         }
-    for (int i = t; i < 512; i += TNT) S[A_XS + i] = 0.0;
+    for (int i = t; i < 768; i += TNT) S[A_XS + i] = 0.0;
     __syncthreads();
-    int cur = 0;
 #define TRD_RUN(KV)                                                                           \
     for (int kk_ = 0; kk_ < 32; ++kk_) {                                                      \
       const int k_ = 32 * (KV) + kk_;                                                         \
-      if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, cur, t, p, q, wp, wq, Hs);                    \
+      if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs);                         \
     }
     TRD_RUN(0) TRD_RUN(1) TRD_RUN(2) TRD_RUN(3) TRD_RUN(4) TRD_RUN(5) TRD_RUN(6) TRD_RUN(7)
 #undef TRD_RUN
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     __syncthreads();
   }
 
+  stamp(1);
   // ================= phase B: the TM largest eigenvalues of T =================
   double2* dd2 = reinterpret_cast<double2*>(sm + L_DD2);
   {
@@ -356,6 +361,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     if (s == 0) sm[L_LAM + r] = 0.5 * (lo + hi);
     __syncthreads();
   }
+  stamp(2);
   const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1], tnorm = sm[L_MISC + M_TN];
   const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
   auto significant = [&](int c) -> bool { const double lc = sm[L_LAM + c]; return lc > 0.0 && (lc - lamcut) > sigtol; };
@@ -376,21 +382,37 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
       const bool act = (t & 7) == 0;
       const int role = (t >> 3) & 1, cl = t >> 4, c = rd * 32 + cl;
       const double lam = sm[L_LAM + c];
+      // (the loops below fetch a batch of operands into registers before each stretch of the dependent chain: only 8 lanes
+      // of a wave work here, what limits them is latency, and a load issued inside the chain would sit in front of it)
       if (act) {
         if (role == 0) {
           double qv = dd2[0].x - lam;
           qp[cl] = qv;
-          for (int i = 1; i < TN; ++i) {
-            const double2 de = dd2[i];
-            qv = fma(-de.y, trd_rcp(guard(qv)), de.x - lam);
-            qp[i * 32 + cl] = qv;
+          for (int i0 = 1; i0 < TN; i0 += 5) {  // 255 = 51 x 5
+            double2 de[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) de[j] = dd2[i0 + j];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              qv = fma(-de[j].y, trd_rcp(guard(qv)), de[j].x - lam);
+              qp[(i0 + j) * 32 + cl] = qv;
+            }
           }
         } else {
           double qv = dd2[TN - 1].x - lam;
           qm[(TN - 1) * 32 + cl] = qv;
-          for (int i = TN - 2; i >= 0; --i) {
-            qv = fma(-dd2[i + 1].y, trd_rcp(guard(qv)), dd2[i].x - lam);
-            qm[i * 32 + cl] = qv;
+          for (int i0 = TN - 2; i0 >= 0; i0 -= 5) {  // i0, i0 - 1, .. i0 - 4: 254 .. 0
+            double dx[5], e2[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              dx[j] = dd2[i0 - j].x - lam;
+              e2[j] = dd2[i0 - j + 1].y;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              qv = fma(-e2[j], trd_rcp(guard(qv)), dx[j]);
+              qm[(i0 - j) * 32 + cl] = qv;
+            }
           }
         }
       }
@@ -399,9 +421,13 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
         const int i0 = role * (TN / 2);
         double best = 1.7976931348623157e308;
         int kt = i0;
-        for (int i = i0; i < i0 + TN / 2; ++i) {
-          const double g = fabs((qp[i * 32 + cl] + qm[i * 32 + cl]) - (dd2[i].x - lam));
-          if (g < best) { best = g; kt = i; }
+        for (int ib = i0; ib < i0 + TN / 2; ib += 8) {
+          double g[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] = fabs((qp[(ib + j) * 32 + cl] + qm[(ib + j) * 32 + cl]) - (dd2[ib + j].x - lam));
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (g[j] < best) { best = g[j]; kt = ib + j; }
         }
         xch[cl * 4 + role] = best;
         xch[cl * 4 + 2 + role] = (double)kt;
@@ -420,16 +446,36 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
         double ss = 0.0, zc = 1.0;
         if (role == 0) {
           Zg[(long)kt * TM + c] = 1.0;
-          for (int i = kt - 1; i >= 0; --i) {
-            zc = -sm[L_E + i] * zc * trd_rcp(guard(qp[i * 32 + cl]));
-            Zg[(long)i * TM + c] = zc;
-            ss = fma(zc, zc, ss);
+          for (int ib = kt - 1; ib >= 0; ib -= 4) {
+            double qq[4], ee[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = ib - j;
+              qq[j] = i >= 0 ? qp[i * 32 + cl] : 1.0;
+              ee[j] = i >= 0 ? sm[L_E + i] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
+              if (ib - j >= 0) Zg[(long)(ib - j) * TM + c] = zc;
+              ss = fma(zc, zc, ss);
+            }
           }
         } else {
-          for (int i = kt + 1; i < TN; ++i) {
-            zc = -sm[L_E + i - 1] * zc * trd_rcp(guard(qm[i * 32 + cl]));
-            Zg[(long)i * TM + c] = zc;
-            ss = fma(zc, zc, ss);
+          for (int ib = kt + 1; ib < TN; ib += 4) {
+            double qq[4], ee[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = ib + j;
+              qq[j] = i < TN ? qm[i * 32 + cl] : 1.0;
+              ee[j] = i < TN ? sm[L_E + i - 1] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
+              if (ib + j < TN) Zg[(long)(ib + j) * TM + c] = zc;
+              ss = fma(zc, zc, ss);
+            }
           }
         }
         xch[cl * 4 + role] = ss;
@@ -445,6 +491,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
       }
     }
     __syncthreads();
+    stamp(3);
     // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
     {
       const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
@@ -459,6 +506,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     }
     __syncthreads();
   }
+  stamp(4);
   if (dbg.d) {
     if (t < TN) { dbg.d[(long)bm * TN + t] = sm[L_D + t]; dbg.e[(long)bm * TN + t] = sm[L_E + t]; }
     if (t < TM) dbg.lam[(long)bm * TM + t] = sm[L_LAM + t];
@@ -475,19 +523,40 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     for (int a = 0; a < 16; ++a)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) Z[a][cb] = Zg[(long)(p + 16 * a) * TM + q + 32 * cb] * sm[L_ZS + q + 32 * cb];
-    __syncthreads();  // scratch region: pivot arrays -> reflector / partial-sum buffers
-    double* vbuf = S + D_VB;
-    double* spb = S + D_SP;
-    if (t < TN) vbuf[t] = Hs[(long)(TN - 3) * TN + t];
+    __syncthreads();  // scratch region: pivot arrays -> reflector blocks / partial-sum buffers
+    // Reflectors are staged in LDS in blocks of 16 (the next block travels from global memory into registers while the
+    // current one is applied), so that a step costs one barrier: s = v^T Z reduced over the thread rows, then Z -= tau v s^T.
+    constexpr int DBK = 16;
+    double* vblk = S + D_VB;   // [2][DBK][256]
+    double* spb = S + D_SP;    // [2][2][128]
+    auto block_fetch = [&](int kb, double (&nx)[8]) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int idx = t + TNT * m, kr = DBK * kb + (idx >> 8);
+        nx[m] = (kb >= 0 && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
+      }
+    };
+    auto block_store = [&](int buf, const double (&nx)[8]) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) vblk[buf * (DBK * 256) + t + TNT * m] = nx[m];
+    };
+    double nx[8];
+    const int kb_top = (TN - 3) / DBK;
+    block_fetch(kb_top, nx);
+    block_store(0, nx);
     __syncthreads();
     int par = 0;
-    for (int k = TN - 3; k >= 0; --k) {
-      const double vnext = (t < TN && k > 0) ? Hs[(long)(k - 1) * TN + t] : 0.0;
-      const double tau = sm[L_TAU + k];
-      double vi[16], s4[4];
-      const double* vb = vbuf + par * 256;
-      double* sp = spb + par * 256;
-      if (tau != 0.0) {
+    for (int kb = kb_top; kb >= 0; --kb) {
+      const int buf = (kb_top - kb) & 1;
+      block_fetch(kb - 1, nx);
+      for (int kr = DBK - 1; kr >= 0; --kr) {
+        const int k = DBK * kb + kr;
+        if (k > TN - 3) continue;
+        const double tau = sm[L_TAU + k];
+        if (tau == 0.0) continue;  // uniform
+        double vi[16], s4[4];
+        const double* vb = vblk + buf * (DBK * 256) + kr * 256;
+        double* sp = spb + par * 256;
         switch ((k + 1) >> 5) {
           case 0: trd_apply<0>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
           case 1: trd_apply<1>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
@@ -498,10 +567,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
           case 6: trd_apply<6>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
           default: trd_apply<7>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
         }
-      }
-      if (t < TN) vbuf[(par ^ 1) * 256 + t] = vnext;
-      __syncthreads();
-      if (tau != 0.0) {
+        __syncthreads();
         switch ((k + 1) >> 5) {
           case 0: trd_apply2<0>(Z, tau, sp, q, vi); break;
           case 1: trd_apply2<1>(Z, tau, sp, q, vi); break;
@@ -512,8 +578,10 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
           case 6: trd_apply2<6>(Z, tau, sp, q, vi); break;
           default: trd_apply2<7>(Z, tau, sp, q, vi); break;
         }
+        par ^= 1;
       }
-      par ^= 1;
+      block_store(buf ^ 1, nx);
+      __syncthreads();
     }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
@@ -528,6 +596,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     }
     if (t == 0) done[bm] = 1;
   }
+  stamp(5);
 }
 
 }  // namespace mused
@@ -551,8 +620,8 @@ int trd_prepare() {
 // lam_j v_j for its 128 largest eigenvalues (descending), columns 128 .. 255 zeros; done[b] = 0 -> untouched (certificate
 // failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.
 int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d, double* dbg_e,
-              double* dbg_lam, double* dbg_res) {
-  TrdDebug dbg{dbg_d, dbg_e, dbg_lam, dbg_res};
+              double* dbg_lam, double* dbg_res, long long* dbg_clk) {
+  TrdDebug dbg{dbg_d, dbg_e, dbg_lam, dbg_res, dbg_clk};
   double* Hs = ws;
   double* Zg = ws + (size_t)batch * TN * TN;
   hipLaunchKernelGGL(trd_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_TOTAL, st, Gc, rep, done, Hs, Zg, dbg);
@@ -584,7 +653,8 @@ extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_
 
 // Diagnostic: average time (ms, HIP events) of `reps` direct solves of the same `batch` matrices (G is restored from a
 // copy before every solve; the copy is outside the timed region).
-extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double* out_ms, int* out_done, void* stream) {
+extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double* out_ms, int* out_done, long long* out_clk,
+                                    void* stream) {
   MUSED_REQUIRE(G && batch >= 1 && reps >= 1 && out_ms, "mused_debug_trd_time: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int rc = trd_prepare();
@@ -602,7 +672,7 @@ extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double
   for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
     MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
     MUSED_CHECK_HIP(hipEventRecord(e0, st));
-    rc = trd_solve(work, batch, nullptr, done, ws, st);
+    rc = trd_solve(work, batch, nullptr, done, ws, st, nullptr, nullptr, nullptr, nullptr, out_clk);
     MUSED_CHECK_HIP(hipEventRecord(e1, st));
     MUSED_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -11,10 +11,14 @@ Gs = fd_buffers("blob", 6)[1:]  # steady-state buffers (kept rows + a new block)
 L = _lib.lib()
 fn = L.mused_debug_trd_time
 fn.restype = C.c_int
-fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]
 for batch in [int(a) for a in sys.argv[1:]] or [1, 28, 112, 224, 256, 280, 512]:
     G = torch.from_numpy(np.stack([Gs[i % len(Gs)] for i in range(batch)])).cuda()
     ms = C.c_double()
     done = (C.c_int * batch)()
-    _lib.check(fn(ptr(G), batch, 5, C.byref(ms), done, stream_ptr()))
-    print(f"batch {batch:4d}: {ms.value:8.3f} ms per solve   ({sum(done)} of {batch} certified)", flush=True)
+    clk = torch.zeros(batch, 8, dtype=torch.int64, device="cuda")
+    _lib.check(fn(ptr(G), batch, 5, C.byref(ms), done, ptr(clk), stream_ptr()))
+    c = clk.cpu().numpy().astype(np.float64)
+    ph = np.diff(c[:, :6], axis=1).mean(axis=0) * 1e-2  # 100 MHz ticks -> us
+    print(f"batch {batch:4d}: {ms.value:8.3f} ms per solve   ({sum(done)} of {batch} certified)   phases us: "
+          f"A tridiag {ph[0]:.0f}  B eigenvalues {ph[1]:.0f}  C vectors {ph[2]:.0f}  certificate {ph[3]:.0f}  D back-transform {ph[4]:.0f}", flush=True)
