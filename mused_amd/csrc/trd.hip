@@ -377,10 +377,12 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     double* xch = sm + L_MISC + 16;  // [32][4] exchange between the two lanes of a vector (scratch S is full)
     for (int rd = 0; rd < TM / 32; ++rd) {
       __syncthreads();  // the previous round's pivot arrays are free (and *badflag is initialised)
-      // lanes 0 and 8 of every 16: role 0 runs the forward pivots and the part of the vector above the twist index, role 1
-      // the backward pivots and the part below -- two dependent chains of 255 divisions side by side instead of one of 1,020
+      // Two lanes per vector, in DIFFERENT waves (the two roles are divergent code: inside one wave they would run one
+      // after the other): waves 0-3 run the forward pivots and the part of the vector above the twist index (role 0),
+      // waves 4-7 the backward pivots and the part below (role 1) -- two dependent chains of 255 divisions side by side
+      // instead of one of 1,020.  8 vectors per wave (every 8th lane).
       const bool act = (t & 7) == 0;
-      const int role = (t >> 3) & 1, cl = t >> 4, c = rd * 32 + cl;
+      const int role = w >> 2, cl = (w & 3) * 8 + (l >> 3), c = rd * 32 + cl;
       const double lam = sm[L_LAM + c];
       // (the loops below fetch a batch of operands into registers before each stretch of the dependent chain: only 8 lanes
       // of a wave work here, what limits them is latency, and a load issued inside the chain would sit in front of it)
