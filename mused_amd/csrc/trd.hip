@@ -37,7 +37,7 @@ constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][25
 // phase C scratch
 constexpr int C_QP = 0 /* [256][32] */, C_QM = 8192;
 // phase D scratch
-constexpr int D_VB = 0 /* [2][16][256] */, D_SP = 8192 /* [2][2][128] */;
+constexpr int D_VB = 0 /* [2][16][256] */, D_SP = 8192 /* [2][2][32][26] */;
 // misc slots
 constexpr int M_GL = 0, M_GU = 1, M_PIV = 2, M_TN = 3;
 
@@ -217,37 +217,77 @@ __device__ __forceinline__ int trd_sturm(const double2* __restrict__ dd2, double
   return cnt;
 }
 
-// ---- phase D: one reflector applied to the 256 x 128 eigenvector block; KD = (k + 1) / 32: rows below 32 KD are untouched -----
+// ---- phase D: FOUR reflectors H_k0 H_k0+1 H_k0+2 H_k0+3 applied to the 256 x 128 eigenvector block per barrier ------------
+// Z <- H_0 H_1 H_2 H_3 Z (H_3 first).  With s_r = v_r^T Z (of the Z before the block) and g_rs = v_r^T v_s, the coefficient
+// rows are  c_3 = tau_3 s_3,  c_2 = tau_2 (s_2 - g_23 c_3),  c_1 = tau_1 (s_1 - g_12 c_2 - g_13 c_3),
+// c_0 = tau_0 (s_0 - g_01 c_1 - g_02 c_2 - g_03 c_3)  and  Z <- Z - sum_r v_r c_r: one reduction (16 + 6 sums per
+// thread column) and one barrier for four rank-1 updates.  KD = (k0 + 1) / 32: rows below 32 KD are untouched.
+constexpr int D_SPQ = 26;  // doubles per thread column in the partial-sum buffer (24 used; 26 keeps 16-byte reads conflict free)
 template <int KD>
-__device__ __forceinline__ void trd_apply(double (&Z)[16][4], const double tau, const double* __restrict__ vb,
-                                          double* __restrict__ sp, const int p, const int q, const int wp, const int l,
-                                          double (&vi)[16], double (&s)[4]) {
+__device__ __forceinline__ void trd_block_dots(const double (&Z)[16][4], const double* __restrict__ vb, double* __restrict__ sp,
+                                               const int p, const int q, const int wp, const int l) {
+  double acc[24];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) s[cb] = 0.0;
+  for (int e = 0; e < 24; ++e) acc[e] = 0.0;
 #pragma unroll
   for (int a = 2 * KD; a < 16; ++a) {
-    vi[a] = vb[p + 16 * a];
+    double v[4];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) s[cb] = fma(vi[a], Z[a][cb], s[cb]);
+    for (int r = 0; r < 4; ++r) v[r] = vb[r * 256 + p + 16 * a];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[4 * r + cb] = fma(v[r], Z[a][cb], acc[4 * r + cb]);
+    acc[16] = fma(v[0], v[1], acc[16]);
+    acc[17] = fma(v[0], v[2], acc[17]);
+    acc[18] = fma(v[0], v[3], acc[18]);
+    acc[19] = fma(v[1], v[2], acc[19]);
+    acc[20] = fma(v[1], v[3], acc[20]);
+    acc[21] = fma(v[2], v[3], acc[21]);
   }
-  // sum over the 8 lanes that differ in lane bits 3-5 (lp); lane ends with column block 2 * bit5 + bit4
-  s[0] = swap32_add(s[0], s[2]);
-  s[1] = swap32_add(s[1], s[3]);
-  s[0] = swap16_add(s[0], s[1]);
-  s[0] = s[0] + dpp_mov_f64<DPP_ROW_ROR8>(s[0]);
-  if ((l & 8) == 0) sp[wp * 128 + q + 32 * (((l >> 5) & 1) * 2 + ((l >> 4) & 1))] = s[0];
-  (void)tau;
+  // sum over the 8 lanes that differ in lane bits 3-5 (the thread rows of a wave), transposing: 24 -> 12 -> 6 -> 3 per lane
+#pragma unroll
+  for (int e = 0; e < 12; ++e) acc[e] = swap32_add(acc[e], acc[e + 12]);
+#pragma unroll
+  for (int e = 0; e < 6; ++e) acc[e] = swap16_add(acc[e], acc[e + 6]);
+  const bool h3 = (l & 8) != 0;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const double keep = h3 ? acc[e + 3] : acc[e], send = h3 ? acc[e] : acc[e + 3];
+    acc[e] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+  }
+  const int base = ((l >> 5) & 1) * 12 + ((l >> 4) & 1) * 6 + (h3 ? 3 : 0);
+  double* dst = sp + (wp * 32 + q) * D_SPQ + base;
+  dst[0] = acc[0];
+  dst[1] = acc[1];
+  dst[2] = acc[2];
 }
 template <int KD>
-__device__ __forceinline__ void trd_apply2(double (&Z)[16][4], const double tau, const double* __restrict__ sp, const int q,
-                                           const double (&vi)[16]) {
-  double sc[4];
+__device__ __forceinline__ void trd_block_update(double (&Z)[16][4], const double* __restrict__ vb, const double* __restrict__ sp,
+                                                 const double* __restrict__ tau4, const int p, const int q) {
+  double sv[24];
+  const double* s0 = sp + q * D_SPQ;
+  const double* s1 = sp + (32 + q) * D_SPQ;
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) sc[cb] = tau * (sp[q + 32 * cb] + sp[128 + q + 32 * cb]);
+  for (int e = 0; e < 22; ++e) sv[e] = s0[e] + s1[e];
+  const double t0 = tau4[0], t1 = tau4[1], t2 = tau4[2], t3 = tau4[3];
+  double c[4][4];
 #pragma unroll
-  for (int a = 2 * KD; a < 16; ++a)
+  for (int cb = 0; cb < 4; ++cb) {
+    c[3][cb] = t3 * sv[12 + cb];
+    c[2][cb] = t2 * fma(-sv[21], c[3][cb], sv[8 + cb]);
+    c[1][cb] = t1 * fma(-sv[20], c[3][cb], fma(-sv[19], c[2][cb], sv[4 + cb]));
+    c[0][cb] = t0 * fma(-sv[18], c[3][cb], fma(-sv[17], c[2][cb], fma(-sv[16], c[1][cb], sv[cb])));
+  }
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) Z[a][cb] = fma(-vi[a], sc[cb], Z[a][cb]);
+  for (int a = 2 * KD; a < 16; ++a) {
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = vb[r * 256 + p + 16 * a];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      Z[a][cb] = fma(-v[0], c[0][cb], fma(-v[1], c[1][cb], fma(-v[2], c[2][cb], fma(-v[3], c[3][cb], Z[a][cb]))));
+  }
 }
 
 struct TrdDebug {
@@ -530,7 +570,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     // current one is applied), so that a step costs one barrier: s = v^T Z reduced over the thread rows, then Z -= tau v s^T.
     constexpr int DBK = 16;
     double* vblk = S + D_VB;   // [2][DBK][256]
-    double* spb = S + D_SP;    // [2][2][128]
+    double* spb = S + D_SP;    // [2][2][32][D_SPQ]
     auto block_fetch = [&](int kb, double (&nx)[8]) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -551,34 +591,32 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
     for (int kb = kb_top; kb >= 0; --kb) {
       const int buf = (kb_top - kb) & 1;
       block_fetch(kb - 1, nx);
-      for (int kr = DBK - 1; kr >= 0; --kr) {
-        const int k = DBK * kb + kr;
-        if (k > TN - 3) continue;
-        const double tau = sm[L_TAU + k];
-        if (tau == 0.0) continue;  // uniform
-        double vi[16], s4[4];
-        const double* vb = vblk + buf * (DBK * 256) + kr * 256;
-        double* sp = spb + par * 256;
-        switch ((k + 1) >> 5) {
-          case 0: trd_apply<0>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          case 1: trd_apply<1>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          case 2: trd_apply<2>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          case 3: trd_apply<3>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          case 4: trd_apply<4>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          case 5: trd_apply<5>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          case 6: trd_apply<6>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
-          default: trd_apply<7>(Z, tau, vb, sp, p, q, wp, l, vi, s4); break;
+      for (int k4 = DBK / 4 - 1; k4 >= 0; --k4) {
+        const int k0 = DBK * kb + 4 * k4;  // reflectors k0 .. k0 + 3 (beyond TN - 3: zero vectors, tau = 0)
+        const double* tau4 = sm + L_TAU + k0;
+        if (tau4[0] == 0.0 && tau4[1] == 0.0 && tau4[2] == 0.0 && tau4[3] == 0.0) continue;  // uniform
+        const double* vb = vblk + buf * (DBK * 256) + 4 * k4 * 256;
+        double* sp = spb + par * (2 * 32 * D_SPQ);
+        switch ((k0 + 1) >> 5) {
+          case 0: trd_block_dots<0>(Z, vb, sp, p, q, wp, l); break;
+          case 1: trd_block_dots<1>(Z, vb, sp, p, q, wp, l); break;
+          case 2: trd_block_dots<2>(Z, vb, sp, p, q, wp, l); break;
+          case 3: trd_block_dots<3>(Z, vb, sp, p, q, wp, l); break;
+          case 4: trd_block_dots<4>(Z, vb, sp, p, q, wp, l); break;
+          case 5: trd_block_dots<5>(Z, vb, sp, p, q, wp, l); break;
+          case 6: trd_block_dots<6>(Z, vb, sp, p, q, wp, l); break;
+          default: trd_block_dots<7>(Z, vb, sp, p, q, wp, l); break;
         }
         __syncthreads();
-        switch ((k + 1) >> 5) {
-          case 0: trd_apply2<0>(Z, tau, sp, q, vi); break;
-          case 1: trd_apply2<1>(Z, tau, sp, q, vi); break;
-          case 2: trd_apply2<2>(Z, tau, sp, q, vi); break;
-          case 3: trd_apply2<3>(Z, tau, sp, q, vi); break;
-          case 4: trd_apply2<4>(Z, tau, sp, q, vi); break;
-          case 5: trd_apply2<5>(Z, tau, sp, q, vi); break;
-          case 6: trd_apply2<6>(Z, tau, sp, q, vi); break;
-          default: trd_apply2<7>(Z, tau, sp, q, vi); break;
+        switch ((k0 + 1) >> 5) {
+          case 0: trd_block_update<0>(Z, vb, sp, tau4, p, q); break;
+          case 1: trd_block_update<1>(Z, vb, sp, tau4, p, q); break;
+          case 2: trd_block_update<2>(Z, vb, sp, tau4, p, q); break;
+          case 3: trd_block_update<3>(Z, vb, sp, tau4, p, q); break;
+          case 4: trd_block_update<4>(Z, vb, sp, tau4, p, q); break;
+          case 5: trd_block_update<5>(Z, vb, sp, tau4, p, q); break;
+          case 6: trd_block_update<6>(Z, vb, sp, tau4, p, q); break;
+          default: trd_block_update<7>(Z, vb, sp, tau4, p, q); break;
         }
         par ^= 1;
       }
