@@ -158,3 +158,27 @@ def test_fd_rotation_through_the_plan_matches_svd():
     np.testing.assert_allclose(got[: keep.sum()], ref[keep], rtol=0, atol=1e-9 * s[0])
     B = t.cpu().numpy()[:ell]
     np.testing.assert_allclose(B.T @ B, (Vt[:ell].T * np.where(keep, ref ** 2, 0)) @ Vt[:ell], rtol=0, atol=1e-9 * lam[0])
+
+
+def test_rejected_matrices_go_through_the_jacobi_fallback():
+    """A buffer whose Gram matrix has a 100-fold eigenvalue above the cut: the direct solver's certificate rejects it, the
+    queue Jacobi of the same plan solves it (mused_fd_rotate -> SWFD rotation plan), and the result equals the SVD's."""
+    from mused_amd import _lib
+    from mused_amd.engine import ptr, stream_ptr
+
+    rng = np.random.default_rng(7)
+    ell, dd = 128, 512
+    Q = np.linalg.qr(rng.standard_normal((dd, 2 * ell)))[0].T          # 256 orthonormal rows
+    s = np.r_[np.full(100, 5.0), np.linspace(4.0, 0.5, 156)]
+    buf = (np.linalg.qr(rng.standard_normal((256, 256)))[0] * s) @ Q   # singular values s, 100 of them equal
+    lam = np.sort(s)[::-1] ** 2
+    ref = np.sqrt(np.maximum(lam[:ell] - lam[ell - 1], 0))
+    t = torch.from_numpy(buf).cuda()
+    sig = torch.zeros(ell, dtype=torch.float64, device="cuda")
+    _lib.call("mused_fd_rotate", ptr(t), ell, dd, ptr(sig), 0, stream_ptr())
+    got = np.sort(sig.cpu().numpy())[::-1]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * s.max())
+    B = t.cpu().numpy()[:ell]
+    _, _, Vt = np.linalg.svd(buf, full_matrices=False)
+    # the kept rows span the top directions with the shrunk energies: compare B^T B with the SVD's
+    np.testing.assert_allclose(B.T @ B, (Vt[:ell].T * ref ** 2) @ Vt[:ell], rtol=0, atol=1e-9 * lam[0])
