@@ -386,6 +386,32 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    # ---- the halo: every lane first sketches ONE window it does not own (SWFD MAIN(t) continues AUX(t - 1)); in the layout
+    # above the warm-up windows play that role.  One sketch-only lock-step of all lanes is timed here, with the same
+    # bracket as the timed region, and charged to `value` in proportion: on the 100-window-per-GPU stream of BASELINE
+    # config 2 the K timed windows carry K / 100 of it.
+    t_halo = 0.0
+    if sketches:
+        for sk in sketches:
+            sk.profile(False)   # (the events of the timed region stay readable)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        ths = [threading.Thread(target=drive_sketch, args=(g, T - 1, T)) for g in range(len(sketches))]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_halo = time.perf_counter() - th0
+        thmax = torch.tensor([t_halo], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(thmax, op=dist.ReduceOp.MAX)
+        t_halo = float(thmax.item())
+
     # label chain across ranks (outside the timed region: W ints per window), in stream order
     by_trigger = {tr["trigger"]: tr["raw"] for tr in pipe.trace}
     raw_local = np.array([by_trigger[trigger_of(p, t)] for p in range(B) for t in range(Wu, Wu + blks[p])], dtype=np.int64)
@@ -407,9 +433,10 @@ def main():
         pipe.eng.score_events = None
         gemm_live_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else None
         # the live Jacobi timing covers the timed region only: read it before the stand-alone runs below
-        osj_reads = []
+        osj_reads, trd_reads = [], []
         for sk in sketches:
             osj_reads.append(sk.profile_read())
+            trd_reads.append(sk.profile_read_direct())
             sk.profile(False)
 
         # ---- what ONE stream consumed in order gets: a single-lane sketch beside the main path, window by window ----
@@ -462,7 +489,68 @@ def main():
         # (orders <= 256; nb = n / 32 column blocks) or nb launches (orders 320-512: one more for the pairs inside the blocks)
         nb = max(2, -(-n2 // 64) * 2)
         flops_per_matrix_launch = (n2 * (n2 - 1) // 2) * (6.0 * n2) / (nb - 1 if n2 <= 256 else nb)
-        if sketches:
+        direct = bool(sketches) and all(r[0] for r in trd_reads)
+        if direct:
+            # dominant kernel by time: trd_kernel (csrc/trd.hip), the direct eigensolver of the FD rotation -- one workgroup
+            # (one CU) per Gram matrix of order 256: Householder tridiagonalisation, 128 eigenvalues by multisection on Sturm
+            # counts, their vectors by twisted factorisation, back-transformation.  fp64 VALU, no MFMA: what bounds it is
+            # the dependent steps (4 workgroup barriers per column of the reduction, ~255 columns), not bytes.
+            n = n2
+            m_top = ell
+            flop_solve = {
+                "tridiagonalisation_4n3_3": 4.0 * n ** 3 / 3.0,
+                "back_transformation_2n2m": 2.0 * n * n * m_top,
+                "sturm_counts_20_passes_x_512_points_x_5flop": 20 * 512 * (n - 1) * 5.0,
+                "twisted_factorisation": m_top * 4.0 * (n - 1) * 6.0,
+            }
+            fl = sum(flop_solve.values())
+            t_ms = sum(r[1] for r in trd_reads)
+            n_launch = sum(r[2] for r in trd_reads)
+            solved = sum(r[3] for r in trd_reads)
+            ns = len(sketches)
+            if n_launch and t_ms > 0:
+                launch_us = 1e3 * t_ms / n_launch
+                per_launch = solved / n_launch
+                tfl = per_launch * fl / (launch_us * 1e-6) / 1e12
+                tr = None
+                try:
+                    pmf = newest_profile("r*_pmc_trd.json")
+                    if pmf:
+                        pm = json.load(open(pmf))
+                        tr = pm["traffic_bytes_per_matrix"] * per_launch
+                except Exception:
+                    tr = None
+                roof = {
+                    "kernel": f"trd_kernel (direct symmetric eigensolver of the FD rotation: one workgroup = one CU per Gram matrix of "
+                              f"order {n}, top {m_top} eigenpairs; fp64 vector ALU, no MFMA), {np.mean([sk.lanes * 2 * sk.L for sk in sketches]):.0f} "
+                              f"matrices per launch of which {per_launch:.1f} are solved (duplicates / frozen sketches skipped), "
+                              f"{ns} independent launch streams",
+                    "bound": "valu",
+                    "achieved": tfl,
+                    "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": tfl / FP64_PEAK_TFLOPS,
+                    "traffic": tr,
+                    "launch_us": launch_us,
+                    "launches_timed": n_launch,
+                    "matrices_solved_per_launch_avg": per_launch,
+                    "flop_per_matrix": flop_solve,
+                    "executed_flops_per_launch": per_launch * fl,
+                    "per_cu": {"achieved_gflops": fl / (launch_us * 1e-6) / 1e9, "peak_gflops": 1e3 * FP64_PEAK_TFLOPS / 256,
+                               "frac": fl / (launch_us * 1e-6) / 1e9 / (1e3 * FP64_PEAK_TFLOPS / 256)},
+                    "concurrent_launch_streams": ns,
+                    "note": "`bound`: the contract's enum is hbm | mfma; this kernel is neither -- fp64 VALU work in a chain of "
+                            "dependent, barrier-separated steps (one CU per matrix), priced on the flops of its four phases "
+                            "against the fp64 vector rate of the chip (78.6 TFLOP/s, the same number as the fp64 MFMA peak).  "
+                            "A launch occupies `matrices_solved_per_launch_avg` of the 256 CUs: `per_cu` is what one busy CU "
+                            "reaches.  algorithmic bytes per matrix: 512 KB read (G) + 256 KB written (128 columns).",
+                }
+                roof_hbm = {
+                    "kernel": "same launches priced on bytes: G read once (512 KB), 128 columns written (256 KB) per matrix",
+                    "bound": "hbm", "achieved": per_launch * 786432.0 / (launch_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": per_launch * 786432.0 / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "launch_us": launch_us,
+                }
+        if sketches and not direct:
             osj_ms = osj_launches = 0
             osj_total_bytes = 0.0
             for ms_g, n_g, b_g in osj_reads:
@@ -551,7 +639,7 @@ def main():
             "algorithmic_flops_per_launch": flops,
             "algorithmic_tflops_equivalent": flops / gemm_s / 1e12,
         }
-        if roof is not None:
+        if roof is not None and not direct:
             # every Jacobi launch of this script (warm-up windows, timed region, stand-alone stage run):
             # the population a `rocprofv3 --kernel-trace --stats -- python3 bench.py` average is taken over
             ms_all = osj_ms + sum(r[0] for r in other_reads)
@@ -560,19 +648,27 @@ def main():
             roof["launches_whole_script"] = n_all
         if roof is None:
             roof = roof_gemm
-        value = world * K * W / elapsed
+        value_excl_halo = world * K * W / elapsed
+        halo_share = t_halo * K / 100.0          # K of the 100 windows a GPU owns in BASELINE config 2
+        value = world * K * W / (elapsed + halo_share)
         # (3) the whole path in SURVEY 8(d) units: algorithmic flop per row (SWFD 12 l d per FD instance, similarity
         #     2 W d per modality, eigenstep 13 * 2 W (l + 10), dense variant) x rows/s against the fp64 peak
         per_row = 0.0
         if sketches:
             per_row += 12.0 * ell * D * (2 * L_sk)
-        per_row += sum(2.0 * W * dm for dm in dims) + 13.0 * 2.0 * W * (ell + 10)
+        per_row += sum(2.0 * W * dm for dm in dims)
+        nnz = W * (k - 1) * M
+        eig_bytes = 13.0 * nnz * (ell + 10) * 8.0          # SURVEY 8(d), neighbour-list SpMM variant (the one that runs)
         roof_8d = {
-            "definition": "SURVEY 8(d) algorithmic flop per row x measured rows/s of one GPU / fp64 peak",
+            "definition": "SURVEY 8(d) algorithmic work per row x measured rows/s of one GPU: SWFD + similarity in flop against "
+                          "the fp64 peak; the eigenstep (13 SpMM by neighbour lists) in bytes against HBM, on its own stage time",
             "mflop_per_row": per_row / 1e6,
             "swfd_fd_instances": 2 * L_sk if sketches else 0,
             "achieved": per_row * (value / world) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": per_row * (value / world) / 1e12 / FP64_PEAK_TFLOPS,
+            "eigenstep": {"bound": "hbm", "algorithmic_bytes_per_window": eig_bytes, "stage_ms_alone": stages["rsvd_ms"],
+                          "achieved": eig_bytes / (stages["rsvd_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": eig_bytes / (stages["rsvd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         sha16 = hashlib.sha256(all_labels.astype(np.int64).tobytes()).hexdigest()[:16]
         golden_ok = None
@@ -591,7 +687,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": Wu,
-            "ms_per_step": 1e3 * elapsed / K,
+            "ms_per_step": 1e3 * (elapsed + halo_share) / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -613,7 +709,11 @@ def main():
             # every lane re-sketches ONE window it does not own (its halo: SWFD MAIN(t) continues AUX(t-1)); the warm-up
             # windows play that role here and are not timed.  On the 100-window-per-GPU stream of BASELINE config 2
             # (1M rows) B lanes cost B extra sketch windows:
-            "value_incl_halo_100win_stream": value * 100.0 / (100.0 + B) if sketches else value,
+            "value_excl_halo": value_excl_halo,
+            "halo": {"lock_step_s": t_halo, "share_charged_s": halo_share, "timed_s": elapsed,
+                     "rule": "value = rows / (timed + halo lock-step x K / 100): every lane sketches one window it does not own "
+                             "before its block; on the 100-window-per-GPU stream of BASELINE config 2 the K timed windows "
+                             "carry K / 100 of that lock-step (measured here: all lanes, sketch only, same bracket)"},
             "stages_ms": stages,
             "roofline": roof,
             "roofline_hbm": roof_hbm,

@@ -1258,6 +1258,24 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
   return MUSED_OK;
 }
 
+int eig_plan_profile_read_direct(EigPlan* p, double* total_ms, long* launches, double* matrices_solved) {
+  *total_ms = 0.0; *launches = 0; *matrices_solved = 0.0;
+  if (!p || !p->trd || !p->ev0) return MUSED_OK;
+  for (int i = 0; i < p->prof_n; ++i) {
+    MUSED_CHECK_HIP(hipEventSynchronize((*p->ev1)[i]));
+    float ms = 0.f;
+    MUSED_CHECK_HIP(hipEventElapsedTime(&ms, (*p->ev0)[i], (*p->ev1)[i]));
+    *total_ms += ms;
+  }
+  *launches = p->prof_n;
+  if (p->work) {
+    unsigned long long w = 0;
+    MUSED_CHECK_HIP(hipMemcpy(&w, p->work, 8, hipMemcpyDeviceToHost));
+    *matrices_solved = (double)w;
+  }
+  return MUSED_OK;
+}
+
 // Column-form access for callers that can use the raw result of the one-sided solver: after
 // eig_plan_run_inplace(p, nullptr, nullptr, ...) column j of matrix b, cols[(b * ld + j) * ld + 0..n), is
 // lam_j u_j and lam[b * ld + j] its norm (the eigenvalue).  Returns false for the two-sided fallback.
@@ -1295,8 +1313,13 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->trd) {
       if (!p->direct) { set_error("eig_plan_run_inplace: the direct solver needs the caller to fill eig_plan_input"); return MUSED_ERR_STATE; }
-      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st);
+      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               rec ? p->work : nullptr);
       if (rc) return rc;
+      if (rec) {  // the events of a direct-solver plan bracket the direct solver alone (the Jacobi behind it only sees rejects)
+        MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
+        ++p->prof_n;
+      }
     }
     if (p->have_graph && allow_graph) {
       MUSED_CHECK_HIP(hipGraphLaunch(p->exec, st));
@@ -1304,7 +1327,7 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
       const int rc = osj_enqueue_sweeps(p, st);
       if (rc) return rc;
     }
-    if (rec) {
+    if (rec && !p->trd) {
       MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
       ++p->prof_n;
       if (p->notconv)

@@ -772,6 +772,17 @@ int mused_swfd_profile_read(void* handle, double* total_ms, long* launches, doub
   return eig_plan_profile_read(h->eig, total_ms, launches, bytes_per_launch);
 }
 
+// As mused_swfd_profile_read for sketches whose rotations run the direct eigensolver (csrc/trd.hip; order 2 l = 256):
+// summed ms of the trd_kernel launches timed since mused_swfd_profile(handle, 1), their number, and the number of matrices
+// they solved.  *direct = 0: this sketch's rotations run the Jacobi (use mused_swfd_profile_read).  BLOCKING.
+extern "C" int mused_swfd_profile_read_direct(void* handle, double* total_ms, long* launches, double* matrices_solved,
+                                              int* direct) {
+  Swfd* h = (Swfd*)handle;
+  MUSED_REQUIRE(h && total_ms && launches && matrices_solved && direct, "mused_swfd_profile_read_direct: null pointer");
+  *direct = eig_plan_direct_solver(h->eig) ? 1 : 0;
+  return eig_plan_profile_read_direct(h->eig, total_ms, launches, matrices_solved);
+}
+
 // Replaces the per-row SeqBasedSWFD.fit(row) loop (main.py:65-67): appends n_rows rows of
 // length d (device pointer, row pitch ld elements, dtype MUSED_F32 / F64 / I64 -- the fused matrix
 // is int64 for >= 2 modalities, matrix_operations.py:138).  Any split of the stream into calls

@@ -296,6 +296,7 @@ struct TrdDebug {
   double* lam;  // batch x 128
   double* res;  // batch x 128: twisted-factorisation residual / |T|
   long long* clk;  // batch x 8: wall_clock64() (100 MHz) at the phase boundaries
+  unsigned long long* work;  // profiling: += 1 per matrix this launch solved (not skipped, not rejected)
 };
 
 __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
@@ -634,7 +635,10 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
         G[(long)(c + TM) * TN + p + 16 * a] = 0.0;
       }
     }
-    if (t == 0) done[bm] = 1;
+    if (t == 0) {
+      done[bm] = 1;
+      if (dbg.work) atomicAdd(dbg.work, 1ull);
+    }
   }
   stamp(5);
 }
@@ -660,8 +664,8 @@ int trd_prepare() {
 // lam_j v_j for its 128 largest eigenvalues (descending), columns 128 .. 255 zeros; done[b] = 0 -> untouched (certificate
 // failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.
 int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d, double* dbg_e,
-              double* dbg_lam, double* dbg_res, long long* dbg_clk) {
-  TrdDebug dbg{dbg_d, dbg_e, dbg_lam, dbg_res, dbg_clk};
+              double* dbg_lam, double* dbg_res, long long* dbg_clk, unsigned long long* work) {
+  TrdDebug dbg{dbg_d, dbg_e, dbg_lam, dbg_res, dbg_clk, work};
   double* Hs = ws;
   double* Zg = ws + (size_t)batch * TN * TN;
   hipLaunchKernelGGL(trd_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_TOTAL, st, Gc, rep, done, Hs, Zg, dbg);
