@@ -58,6 +58,11 @@ WORKLOADS = {
                name="synthetic two modalities d=512+512 l=128 window=10000 k=50 (BASELINE config 4)"),
     # small plumbing case (configs[0] shapes) for quick checks
     "c1": dict(W=500, dims=(64,), ell=16, k=50, lanes=4, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
+    # the reference's OWN use of the sketch (main.py:58-76, approach SWFDMC): SeqBasedSWFD over the rows of the fused W x W
+    # adjacency (d = W = 10,000, bit rows), R from the first window, sketch transposed to (W, l) -> k-means -> matching.
+    # One sketch object for the whole stream: windows are consumed strictly in order (no lanes).
+    "swfdmc": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=1,
+                   name="SWFDMC wiring of main.py:58-76: features d=1024 -> kNN adjacency -> sketch over its W=10000 bit rows, l=128"),
 }
 PRE_STREAM = 1 << 20  # window indices of warm-up windows that would precede window 0 of the stream
 FP64_PEAK_TFLOPS = 78.6  # gfx950: the fp64 vector-FMA peak and the fp64 MFMA peak are the same number
@@ -218,6 +223,92 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
     }
 
 
+def run_swfdmc(args, cfg):
+    """`--workload swfdmc`: the reference's wiring of the sketch at the headline window size, one rank = one in-order stream
+    (rank r: windows [r K, (r + 1) K) of the seeded stream, preceded by `warmup` windows of which the last is its halo)."""
+    import torch
+    import torch.distributed as dist
+
+    from mused_amd.pipeline import StreamPipeline
+    from mused_amd.swfd import SeqBasedSWFD
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("MUSED_DIST_BACKEND", "nccl")
+    if "MUSED_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["MUSED_FORCE_DEVICE"])
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    W, ell, k, d = cfg["W"], cfg["ell"], cfg["k"], cfg["dims"][0]
+    K, Wu = args.steps, max(1, args.warmup)
+    g0 = rank * K
+    idx = [g0 - Wu + t for t in range(Wu + K)]
+    wins = [window_rows(cfg, args.kind, i if i >= 0 else PRE_STREAM - i, args.seed) for i in idx]
+    rows = torch.stack([torch.from_numpy(w[0]) for w in wins]).cuda()
+    pipe = StreamPipeline(W, ell, k, args.seed, "SWFDMC", modality_types=[""], async_labels=True, assume_finite=True)
+    # R of main.py:61 comes from window 0 of the STREAM (every rank computes it from that window: no broadcast needed)
+    x0 = torch.from_numpy(window_rows(cfg, args.kind, 0, args.seed)[0]).cuda()
+    R = pipe.eng.max_row_sq_norm(pipe.eng.knn_adjacency(x0, k))
+    pipe.swfd = SeqBasedSWFD(N=W, R=R, d=W, sketch_dim=ell)
+    for t in range(Wu):
+        pipe.process_window([rows[t]], wins[t][1], trigger=(idx[t] + 1) * W - 1)
+    pipe.flush()
+    n_warm = len(pipe.latencies)
+    pipe.swfd.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(Wu, Wu + K):
+        pipe.process_window([rows[t]], wins[t][1], trigger=(idx[t] + 1) * W - 1)
+    pipe.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    if rank == 0:
+        direct, t_ms, n_launch, solved = pipe.swfd.profile_read_direct()
+        lat = np.array(pipe.latencies[n_warm:])
+        fl = 4.0 * 256 ** 3 / 3 + 2.0 * 256 * 256 * 128 + 20 * 512 * 255 * 5.0 + 128 * 4.0 * 255 * 6.0
+        roof = None
+        if direct and n_launch:
+            us = 1e3 * t_ms / n_launch
+            tfl = (solved / n_launch) * fl / (us * 1e-6) / 1e12
+            roof = {"kernel": "trd_kernel (direct eigensolver of the FD rotation, order 256; see the c2 line)", "bound": "valu",
+                    "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP64_PEAK_TFLOPS, "traffic": None,
+                    "launch_us": us, "launches_timed": n_launch, "matrices_solved_per_launch_avg": solved / n_launch}
+        out = np.asarray(pipe.out[n_warm * W:], dtype=np.int64)
+        print(json.dumps({
+            "metric": "stream rows/sec, SWFDMC wiring (main.py:58-76): kNN adjacency -> SWFD over its 10,000 bit rows -> labels",
+            "value": world * K * W / elapsed, "unit": "rows/s", "n_gpus": world, "steps": K, "warmup": Wu,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": cfg["name"], "stream": args.kind, "W": W, "d_features": d, "d_sketch": W, "l": ell, "k": k,
+                       "swfd_levels": pipe.swfd.L, "R": R,
+                       "parallelism": f"{world} in-order stream block(s), one per GPU; the halo window is the last warm-up window",
+                       "labels_sha16": hashlib.sha256(out.tobytes()).hexdigest()[:16]},
+            "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
+            "roofline": roof,
+            "cpu_baseline": None,
+            "note": "parity of this wiring at W = 10,000: tests/test_gpu_headline_shapes.py (oracle fixtures, PARITY UNPINNED: the "
+                    "reference's swfd submodule is absent)",
+        }))
+    pipe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def newest_profile(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
@@ -226,6 +317,8 @@ def newest_profile(pattern):
 def main():
     args = parse()
     cfg = dict(WORKLOADS[args.workload])
+    if args.workload == "swfdmc":
+        return run_swfdmc(args, cfg)
     W, ell, k, dims = cfg["W"], cfg["ell"], cfg["k"], cfg["dims"]
     D, M = sum(dims), len(dims)
 

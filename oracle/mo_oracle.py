@@ -390,13 +390,14 @@ def process_streaming_data(
             else:
                 reduced, sig, _ = randomized_svd_reduce(fused, reduced_dim, seed)
             clusters = perform_clustering(reduced, n_clusters, seed)
+            if trace is not None:  # (recorded before the matching, which may raise: main.py:331 lets that propagate)
+                trace.append(dict(trigger=i, sigma=np.asarray(sig), raw=np.asarray(clusters), n_clusters=n_clusters,
+                                  reduced=np.asarray(reduced)))
             matched = match_clusters(prev, clusters, method="hungarian", min_overlap=3)
             if matched is None or len(matched) == 0:  # main.py:114-116
                 matched = np.full(window_size, 0)
             if trace is not None:
-                trace.append(
-                    dict(trigger=i, sigma=np.asarray(sig), raw=np.asarray(clusters), matched=np.asarray(matched))
-                )
+                trace[-1]["matched"] = np.asarray(matched)
             prev = matched
             out.extend(matched)
     return np.array(out)

@@ -185,13 +185,21 @@ def case_stream(tag, kind, n, d, W, ell, k, seed, approach="sSVDMC", two_mod=Fal
     )
 
 
-def case_bench_stream(tag, kind, n_windows, W, d, ell, k, seed):
+def case_bench_stream(tag, kind, n_windows, W, d, ell, k, seed, dims=None):
     """Event labels of the reference's own window loop (main.py:13-130, approach sSVDMC) over the first `n_windows`
     windows of the benchmark stream (mused_amd.synth.stream_window): what bench.py's `labels_sha16` is compared with.
-    Stored per window (the chain is sequential from window 0, so any prefix is a valid golden)."""
-    wins = [synth.stream_window(kind, t, W, d, seed) for t in range(n_windows)]
+    Stored per window (the chain is sequential from window 0, so any prefix is a valid golden).  `dims`: several
+    modalities side by side (mused_amd.synth.stream_window_mods, BASELINE config 4), each its own adjacency (main.py:45-56)."""
+    if dims is None:
+        wins = [synth.stream_window(kind, t, W, d, seed) for t in range(n_windows)]
+    else:
+        wins = [synth.stream_window_mods(t, W, dims, seed) for t in range(n_windows)]
     X = np.concatenate([w[0] for w in wins]).astype(np.float64)
     labels = np.concatenate([w[1] for w in wins])
+    mods, c0 = [], 0
+    for dm in (dims or (d,)):
+        mods.append(np.ascontiguousarray(X[:, c0 : c0 + dm]))
+        c0 += dm
     captured = {}
 
     def fake_metrics(results, subset_size, noise_rate, label_mode, sorting, reduced_dim, k_basis,
@@ -202,7 +210,7 @@ def case_bench_stream(tag, kind, n_windows, W, d, ell, k, seed):
     orig = ref_me.compute_all_metrics
     ref_me.compute_all_metrics = fake_metrics
     try:
-        quiet(ref_main.process_streaming_data, {}, [X], [""], W, ell, k, len(np.unique(labels)), seed, "sSVDMC",
+        quiet(ref_main.process_streaming_data, {}, mods, [""] * len(mods), W, ell, k, len(np.unique(labels)), seed, "sSVDMC",
               labels, 1, 0.0, "types", False, 1.5, 2)
     finally:
         ref_me.compute_all_metrics = orig
@@ -341,6 +349,10 @@ def main():
             case_stream("c1_stream_hop4_gauss_s1", "gauss", 2000, 64, 400, 16, 30, 1, ratio=4)
         if "bench_c2_blob_s0" in only:   # bench.py default stream: 20 windows of BASELINE config 2
             case_bench_stream("bench_c2_blob_s0", "blob", 20, 10000, 1024, 128, 50, 0)
+        if "bench_c3_blob_s0" in only:   # bench.py --workload c3: 8 windows of BASELINE config 3
+            case_bench_stream("bench_c3_blob_s0", "blob", 8, 10000, 4096, 256, 50, 0)
+        if "bench_c4_blob_s0" in only:   # bench.py --workload c4: 8 windows of BASELINE config 4 (two 512-d modalities)
+            case_bench_stream("bench_c4_blob_s0", "blob", 8, 10000, 1024, 128, 50, 0, dims=(512, 512))
         if "c3_blob_s0" in only:   # BASELINE config 3 at its real shape
             case_windows("c3_blob_s0", "blob", 10000, 4096, 10000, 256, 50, 0, n_centres=8, sep=2.0)
         if "c4_twomod_s0" in only:  # BASELINE config 4 at its real shape (one of the 8 windows)

@@ -205,6 +205,21 @@ def meta_case(rng, i):
     return f"meta n={n:3d} k={k:2d} " + " ".join(out)
 
 
+def kmeans_ill_posed(emb, nc, seed, labels):
+    """Adjudication of a label difference from the REFERENCE side: is the oracle's own k-means answer stable under a
+    perturbation of its input at the level of one unit in the last place?  If scikit-learn's labels on `emb` change when
+    `emb` is perturbed by 1e-15 of its largest entry (tied assignments: equal or zero embedding rows, equal singular
+    values straddling the cut), the reference's answer is not a function of the window at the precision any fp64
+    implementation -- including another LAPACK build -- can reproduce, and a difference is not a parity failure."""
+    prng = np.random.default_rng(12345)
+    scale = 1e-15 * max(float(np.abs(emb).max()), 1e-300)
+    for _ in range(6):
+        pert = emb + scale * prng.standard_normal(emb.shape)
+        if not np.array_equal(omo.perform_clustering(pert, nc, seed), labels):
+            return True
+    return False
+
+
 def rsvd_case(rng, i):
     """Eigenstep on a random kNN adjacency (one or two modalities OR-fused, some rows without any valid neighbour)."""
     n = int(rng.integers(24, 640))
@@ -240,9 +255,13 @@ def rsvd_case(rng, i):
     lab_o = omo.perform_clustering(emb_o, nc, seed)
     lab_d = mo.perform_clustering(emb_d, nc, seed)
     same = np.array_equal(lab_o, lab_d)
+    if not same:  # allowed only where the reference's own answer is ill-posed (see kmeans_ill_posed)
+        assert kmeans_ill_posed(emb_o, nc, seed, lab_o), (
+            f"rsvd case {i} n={n} k={k} l={ell} seed={seed}: labels differ in {int((lab_o != lab_d).sum())} rows although the "
+            "oracle's k-means is stable under a 1e-15 perturbation of its embedding")
     lab_dev = mo.perform_clustering_on_device(torch.from_numpy(emb_d).cuda(), nc, seed)
     assert np.array_equal(lab_dev, lab_d), f"rsvd case {i}: device k-means differs from scikit-learn on the same embedding"
-    return f"rsvd n={n:3d} k={k:2d} M={M} l={ell:2d} seed={seed:3d} clear={int(clear.sum())}/{ell} labels {'equal' if same else 'DIFFER (' + str(int((lab_o != lab_d).sum())) + ')'}"
+    return f"rsvd n={n:3d} k={k:2d} M={M} l={ell:2d} seed={seed:3d} clear={int(clear.sum())}/{ell} labels {'equal' if same else 'differ in ' + str(int((lab_o != lab_d).sum())) + ' rows: oracle k-means ill-posed (flips under a 1e-15 perturbation)'}"
 
 
 def pipeline_case(rng, i):
@@ -277,37 +296,52 @@ def pipeline_case(rng, i):
     if approach == "SWFDMC":
         from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
         kw["swfd_cls"] = OraSWFD
+    otrace = []
+    ref, ref_err = None, None
     try:
-        ref = omo.process_streaming_data(mods, types_, W, ell, k, seed, approach, labels, step_window_ratio=ratio, **kw)
+        ref = omo.process_streaming_data(mods, types_, W, ell, k, seed, approach, labels, step_window_ratio=ratio, trace=otrace, **kw)
     except ValueError as e:
         # scipy's linear_sum_assignment refuses a cost matrix that passes is_feasible (matrix_operations.py:226-233: no
         # all-inf row or column) but has no complete finite assignment; the reference lets that propagate (main.py:331)
-        try:
-            process_streaming_data({}, mods, types_, W, ell, k, len(np.unique(labels)), seed, approach, labels, ratio, 0.0,
-                                   "types", False, 1.5, 2)
-        except ValueError as e2:
-            assert str(e2) == str(e), f"pipeline case {i}: {e2!r} vs {e!r}"
-            return f"pipe W={W:3d} ratio={ratio} n={n:4d} {approach:6s} types={types_} both raise {e}"
-        if approach == "SWFDMC":  # tied k-means on the transposed sketch (see below): the label chains may part ways
-            return f"pipe W={W:3d} ratio={ratio} n={n:4d} {approach:6s} types={types_} oracle raises {e}, device does not (tied k-means)"
-        raise AssertionError(f"pipeline case {i}: the oracle raised {e!r}, the device pipeline did not")
+        ref_err = e
+    from mused_amd.pipeline import StreamPipeline
+
+    got, got_err, dtrace = None, None, []
+    pipe = StreamPipeline(W, ell, k, seed, approach, list(types_), ratio, async_labels=False)
     try:
-        res = process_streaming_data({}, mods, types_, W, ell, k, len(np.unique(labels)), seed, approach, labels, ratio, 0.0,
-                                     "types", False, 1.5, 2)
+        got = pipe.run(mods, np.asarray(labels))
     except ValueError as e:
-        if approach == "SWFDMC" and "infeasible" in str(e):
-            return f"pipe W={W:3d} ratio={ratio} n={n:4d} {approach:6s} types={types_} device raises {e}, oracle does not (tied k-means)"
-        raise
-    got = np.asarray(res["all_clusters"])
-    assert len(got) == len(ref), f"pipeline case {i}: {len(got)} labels vs {len(ref)}"
-    bad = int((got != np.asarray(ref)).sum())
-    if approach == "SWFDMC" and bad:
-        # k-means on the (W, l) transposed sketch of a sparse 0/1 matrix has exactly tied assignments (many embedding
-        # rows are equal or zero): seen to flip on a sketch that agrees with the oracle's to 3e-16 (case (7, 101)), so
-        # label equality is not asserted for this approach here; sketch parity is what swfd_case checks
-        return f"pipe W={W:3d} ratio={ratio} n={n:4d} l={ell:2d} k={k:2d} {approach:6s} types={types_} labels differ in {bad} (tied k-means)"
-    assert bad == 0, f"pipeline case {i} W={W} ratio={ratio} n={n} l={ell} k={k} types={types_} approach={approach}: {bad} labels differ"
-    return f"pipe W={W:3d} ratio={ratio} n={n:4d} l={ell:2d} k={k:2d} {approach:6s} types={types_} labels equal ({len(ref)})"
+        got_err = e
+    finally:
+        dtrace = list(pipe.trace)
+        try:
+            pipe.close()
+        except ValueError:
+            pass
+    head = f"pipe W={W:3d} ratio={ratio} n={n:4d} l={ell:2d} k={k:2d} {approach:6s} types={types_}"
+    if ref_err is not None and got_err is not None:
+        assert str(got_err) == str(ref_err), f"pipeline case {i}: {got_err!r} vs {ref_err!r}"
+        return f"{head} both raise {ref_err}"
+    if ref_err is None and got_err is None and np.array_equal(np.asarray(got), np.asarray(ref)):
+        return f"{head} labels equal ({len(ref)})"
+    # The outcomes differ (labels, or one side raised).  Label chains are sequential: find the FIRST window whose raw
+    # k-means labels differ and adjudicate it from the reference side -- a difference is accepted only if the oracle's own
+    # k-means at that window is ill-posed (kmeans_ill_posed); everything after that window follows from it.
+    first = None
+    for w_, (do, dd) in enumerate(zip(otrace, dtrace)):
+        if not np.array_equal(np.asarray(do["raw"]), np.asarray(dd["raw"])):
+            first = w_
+            break
+    if first is None and len(dtrace) < len(otrace):
+        first = len(dtrace)  # the device raised at this window (its trace records a window after the matching)
+    assert first is not None, (f"pipeline case {i} {head}: outcomes differ (oracle: {ref_err!r}, device: {got_err!r}) although "
+                               "every window's raw k-means labels agree")
+    o = otrace[first]
+    assert kmeans_ill_posed(o["reduced"], o["n_clusters"], seed, o["raw"]), (
+        f"pipeline case {i} {head}: raw labels differ at window {first} although the oracle's k-means there is stable under "
+        "a 1e-15 perturbation of its input")
+    what = "labels differ" if (ref_err is None and got_err is None) else f"oracle: {ref_err!r}, device: {got_err!r}"
+    return f"{head} {what} from window {first} on: oracle k-means ill-posed there (flips under a 1e-15 perturbation)"
 
 
 CASES = {"swfd": swfd_case, "knn": knn_case, "rsvd": rsvd_case, "pipe": pipeline_case, "lanes": lanes_case, "meta": meta_case}
