@@ -188,6 +188,16 @@ __global__ __launch_bounds__(256) void trsm_rows_kernel(const double* __restrict
   }
 }
 
+// out = Y - T  (n x c panels, row pitches ldy / ldt / ldo): the projection step of the blocked Cholesky-QR
+__global__ void panel_sub_kernel(const double* __restrict__ Y, long ldy, const double* __restrict__ T, long ldt, int n, int c,
+                                 double* __restrict__ out, long ldo) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c) return;
+  const long i = gid / c;
+  const int j = (int)(gid - i * c);
+  out[i * ldo + j] = Y[i * ldy + j] - T[i * ldt + j];
+}
+
 __global__ void gram_reduce_kernel(const double* __restrict__ partial, int nsplit, int rc, double* __restrict__ G) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= rc * rc) return;
@@ -295,20 +305,38 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
     const char* e = getenv("MUSED_RSVD_NORMALIZER");
     return e && (e[0] == 'l' || e[0] == 'L');
   }();
-  const bool cholqr = !want_lu && h->mode != 2 && r <= CHOLQR_MAX_R && r <= n;
-  if (cholqr) {
+  const bool cholqr = !want_lu && h->mode != 2 && r <= 2 * CHOLQR_MAX_R && r <= n;
+  // dst = an orthonormal-ish basis of span(Y) by Cholesky-QR; weak (optional device int): raised on a weak pivot.
+  //   r <= CHOLQR_MAX_R:  G = Y^T Y in U;  L = chol(G + delta I) packed in Cm;  dst = Y L^-T
+  //   larger r (BASELINE config 3: r = 266; two packed triangles of that order do not fit the LDS): the columns in two
+  //   halves, block Gram-Schmidt -- Q1 = cholqr(Y1);  Y2' = Y2 - Q1 (Q1^T Y2);  Q2 = cholqr(Y2') -- from the same kernels
+  //   plus two GEMMs.  One projection leaves Q1^T Q2 ~ cond(Y) eps: fine for the normaliser of a power iteration; the final
+  //   basis runs the whole routine twice, which restores orthogonality to rounding as Cholesky-QR2 does.
+  auto normalise = [&](const double* Y, double* dst, int* weak) -> int {
     const int nsp = cdiv(n, CHOLQR_KCHUNK);
-    const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
-    const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(r | 1);
-    // G = Y^T Y in U;  L = chol(G + delta I) packed in Cm;  dst = Y L^-T
-    auto normalise = [&](const double* Y, double* dst) -> int {
+    auto cholqr_block = [&](const double* Yb, int rb, double* dstb) -> int {
       int e;
-      if ((e = gemm_f64_splitk(false, false, Y, ld, Y, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st))) return e;
-      hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)r * r, 256)), dim3(256), 0, st, h->gpart, nsp, r, h->U);
-      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, r, h->Cm, (int*)nullptr);
-      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, Y, ld, n, r, h->Cm, dst, ld);
+      const size_t lds_l = sizeof(double) * (size_t)rb * (rb + 1) / 2;
+      const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(rb | 1);
+      if ((e = gemm_f64_splitk(false, false, Yb, ld, Yb, ld, h->gpart, rb, rb, n, CHOLQR_KCHUNK, nsp, st))) return e;
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)rb * rb, 256)), dim3(256), 0, st, h->gpart, nsp, rb, h->U);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, rb, h->Cm, weak);
+      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, Yb, ld, n, rb, h->Cm, dstb, ld);
       return MUSED_OK;
     };
+    if (r <= CHOLQR_MAX_R) return cholqr_block(Y, r, dst);
+    const int r1 = r / 2, r2 = r - r1;
+    int e;
+    if ((e = cholqr_block(Y, r1, dst))) return e;                                   // Q1 -> dst[:, :r1]
+    double* P = h->Cm + 16384;                                                      // r1 x r2 (behind the packed L)
+    if ((e = gemm_f64_splitk(false, false, dst, ld, Y + r1, ld, h->gpart, r1, r2, n, CHOLQR_KCHUNK, nsp, st))) return e;
+    if ((e = gemm_splitk_reduce(h->gpart, nsp, (long)r1 * r2, P, st))) return e;   // P = Q1^T Y2
+    if ((e = gemm_f64(true, false, dst, ld, 0, P, r2, 0, h->Vsel, r2, 0, n, r2, r1, 1, 1.0, st))) return e;  // Q1 P
+    hipLaunchKernelGGL(panel_sub_kernel, dim3(cdiv((long)n * r2, 256)), dim3(256), 0, st, Y + r1, ld, h->Vsel, (long)r2, n, r2,
+                       dst + r1, ld);                                               // Y2' -> dst[:, r1:]
+    return cholqr_block(dst + r1, r2, dst + r1);                                    // Q2 (in place: a workgroup owns its rows)
+  };
+  if (cholqr) {
     // ONE normalisation per power iteration, of A^T (A Q): the two products in a row square the spread of the basis
     // ((sigma_1 / sigma_r)^2 ~ 1e3 .. 1e4 for these adjacency matrices), far inside what a Cholesky of the Gram takes
     // (1e-11 of the largest pivot is the alarm level), and the subspace is the same (goldens: sigma 1e-15, labels equal)
@@ -317,7 +345,7 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
       RC(spmm_binary(h->rowptr, h->colidx, n, Qcur, ld, rc, X, ld, st));
       double* Z = (X == h->Qa) ? h->Qb : h->Qa;  // (the buffer of the old basis, unless that is Q0)
       RC(spmm_binary(h->rowptrT, h->colidxT, n, X, ld, rc, Z, ld, st));
-      RC(normalise(Z, X));
+      RC(normalise(Z, X, nullptr));
       Qcur = X;
     }
   } else {
@@ -337,16 +365,10 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
   if (cholqr) {
     // final orthonormal basis: Cholesky-QR twice (Yf -> Yt -> Qf); a weak pivot in either pass raises flags[2] (mode 0:
     // the Householder chain below, otherwise a string of no-op launches, then recomputes Qf from the untouched Yf)
-    const int nsp = cdiv(n, CHOLQR_KCHUNK);
-    const size_t lds_l = sizeof(double) * (size_t)r * (r + 1) / 2;
-    const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(r | 1);
     const double* src = Yf;
     double* dsts[2] = {Yt, h->Qf};
     for (int pass = 0; pass < 2; ++pass) {
-      RC(gemm_f64_splitk(false, false, src, ld, src, ld, h->gpart, r, r, n, CHOLQR_KCHUNK, nsp, st));
-      hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)r * r, 256)), dim3(256), 0, st, h->gpart, nsp, r, h->U);
-      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, r, h->Cm, h->flags + 2);
-      hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, src, ld, n, r, h->Cm, dsts[pass], ld);
+      RC(normalise(src, dsts[pass], h->flags + 2));
       src = dsts[pass];
     }
     if (h->mode == 0) RC(qr_economic(Yf, n, rc, ld, h->Qf, ld, h->tau, h->wpart, st, h->flags + 2));
@@ -413,7 +435,7 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
   const size_t words = (n_max + 63) / 64;
   const size_t panel = sizeof(double) * (size_t)n_max * r_max;
   // partial Grams: the final Gram's splits, or the normaliser's finer ones when it can run (r <= CHOLQR_MAX_R)
-  const int nsplit = r_max <= CHOLQR_MAX_R ? cdiv(n_max, CHOLQR_KCHUNK) : cdiv(n_max, GRAM_KCHUNK);
+  const int nsplit = r_max <= 2 * CHOLQR_MAX_R ? cdiv(n_max, CHOLQR_KCHUNK) : cdiv(n_max, GRAM_KCHUNK);
 #define ALLOC(p, bytes) MUSED_CHECK_HIP(hipMalloc((void**)&(p), (bytes)))
   ALLOC(h->mask, 8 * words * n_max);
   ALLOC(h->mask_t, 8 * words * n_max);
