@@ -1,7 +1,7 @@
 """Reduce a rocprofv3 --pmc counter_collection.csv to per-kernel averages (small JSON on stdout)."""
 import csv, glob, json, sys, collections
 d = sys.argv[1]
-f = glob.glob(d + "/*/*counter_collection.csv")[0]
+f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(f)):
     k = (r["Kernel_Name"].split("(")[0][:90], r["Counter_Name"], r["Grid_Size"])
