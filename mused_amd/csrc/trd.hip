@@ -43,6 +43,11 @@ constexpr int M_GL = 0, M_GU = 1, M_PIV = 2, M_TN = 3;
 
 __host__ __device__ constexpr int tidx(int a, int b) { return a * (a + 1) / 2 + b; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's GLOBAL stores (s_waitcnt
+// vmcnt(0)): inside the step loops that would put the latency of a store nobody reads before a later phase (the
+// Householder vectors, the tridiagonal eigenvectors) -- or of a prefetch -- in front of every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double trd_rcp(double y) {  // reciprocal to rounding: hardware seed (~5e-8) + two Newton steps
   double r = __builtin_amdgcn_rcp(y);
   r = fma(fma(-y, r, 1.0), r, r);
@@ -58,10 +63,18 @@ __device__ __forceinline__ double trd_rcp1(double y) {  // one Newton step: ~3e-
 // Four workgroup barriers per step: column k -> LDS | Householder vector v -> LDS | partial sums of y = A v (and of v . y)
 // -> LDS | w -> LDS.  v and w are stored as plain vectors (zeros where the reflector does not act), so that the 2 x 36
 // register elements of a thread are updated from unconditional LDS reads.
+#ifdef TRD_STEP_PROFILE
+#define TRD_TICK(i) do { const long long now_ = clock64(); prof[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define TRD_TICK(i) do { } while (0)
+#endif
 template <int K>
 __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double* __restrict__ sm, const int t, const int p,
-                                         const int q, const int wp, const int wq, double* __restrict__ Hs) {
+                                         const int q, const int wp, const int wq, double* __restrict__ Hs, long long* prof) {
   const int kk = k & 31, l = t & 63;
+#ifdef TRD_STEP_PROFILE
+  long long last_ = clock64();
+#endif
   double* S = sm + L_S;
   double* xs = S + A_XS;
   double* vs = S + A_VS;
@@ -74,7 +87,8 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
       for (int a = K; a < 8; ++a) xs[p + 16 * u + 32 * a] = (a == K ? 2.0 : 1.0) * A[u][tidx(a, K)];
     if (p == (k & 15)) sm[L_D + k] = 2.0 * ((kk >> 4) ? A[1][tidx(K, K)] : A[0][tidx(K, K)]);
   }
-  __syncthreads();
+  lds_barrier();
+  TRD_TICK(0);
   // (2) Householder vector (dlarfg), every wave on its own: beta = -sign(x0) |x|, tau = (beta - x0) / beta, v = x / (x0 - beta)
   double sq = 0.0;
 #pragma unroll
@@ -105,7 +119,8 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
       sm[L_TAU + k] = tau;
     }
   }
-  __syncthreads();
+  lds_barrier();
+  TRD_TICK(1);
   if (tau == 0.0) return;  // H = I (uniform over the workgroup: every thread computed the same scalars from the same data)
   // (3) y = A v over the stored elements: row part r (to be summed over q) and column part c (to be summed over p).
   //     v . y = v^T A v = 2 sum over the stored elements of H_ij v_i v_j = 2 sum_threads sum_rows v_i r_i: no second pass.
@@ -170,7 +185,9 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
     dpart = wave_allsum(dpart);
     if (l == 0) S[A_RED + (t >> 6)] = dpart;
   }
-  __syncthreads();
+  TRD_TICK(2);
+  lds_barrier();
+  TRD_TICK(3);
   // (5) y_i -> w_i = tau y_i - (tau^2 / 2) (v . y) v_i
   if (t < TN) {
     const double* rp = S + A_RP;
@@ -181,7 +198,8 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
     const double alpha = -0.5 * tau * tau * dot;
     ws[t] = t > k ? fma(tau, y, alpha * vs[t]) : 0.0;
   }
-  __syncthreads();
+  lds_barrier();
+  TRD_TICK(4);
   // (6) A <- A - v w^T - w v^T   (diagonal blocks are held at half weight); one grid-row half (u) at a time
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -200,6 +218,7 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
         A[u][tidx(a, b)] = fma(-vi[a], (a == b) ? wjh : wj, fma(-wi[a], (a == b) ? vjh : vj, A[u][tidx(a, b)]));
     }
   }
+  TRD_TICK(5);
 }
 
 // number of eigenvalues of T below x (negative pivots of the LDL^T of T - x I); dd2[i] = {d_i, e_{i-1}^2}
@@ -295,7 +314,7 @@ struct TrdDebug {
   double* e;    // batch x 256
   double* lam;  // batch x 128
   double* res;  // batch x 128: twisted-factorisation residual / |T|
-  long long* clk;  // batch x 8: wall_clock64() (100 MHz) at the phase boundaries
+  long long* clk;  // batch x 16: wall_clock64() (100 MHz) at the phase boundaries [0..5]; TRD_STEP_PROFILE: cycles per step part [8..13]
   unsigned long long* work;  // profiling: += 1 per matrix this launch solved (not skipped, not rejected)
 };
 
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
   double* Zg = Zg_all + (long)bm * TN * TM;
   double* S = sm + L_S;
 
-  auto stamp = [&](int i) { if (dbg.clk && t == 0) dbg.clk[(long)bm * 8 + i] = wall_clock64(); };
+  auto stamp = [&](int i) { if (dbg.clk && t == 0) dbg.clk[(long)bm * 16 + i] = wall_clock64(); };
   stamp(0);
   // ================= phase A: tridiagonalisation =================
   {
@@ -332,13 +351,18 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
         }
     for (int i = t; i < 768; i += TNT) S[A_XS + i] = 0.0;
     __syncthreads();
+    long long prof[6] = {0, 0, 0, 0, 0, 0};
 #define TRD_RUN(KV)                                                                           \
     for (int kk_ = 0; kk_ < 32; ++kk_) {                                                      \
       const int k_ = 32 * (KV) + kk_;                                                         \
-      if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs);                         \
+      if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs, prof);                   \
     }
     TRD_RUN(0) TRD_RUN(1) TRD_RUN(2) TRD_RUN(3) TRD_RUN(4) TRD_RUN(5) TRD_RUN(6) TRD_RUN(7)
 #undef TRD_RUN
+#ifdef TRD_STEP_PROFILE
+    if (dbg.clk && t == 0)
+      for (int i = 0; i < 6; ++i) dbg.clk[(long)bm * 16 + 8 + i] = prof[i];
+#endif
     if (p == 15 && q == 31) sm[L_D + TN - 1] = 2.0 * A[1][tidx(7, 7)];
     if (t == 0) { sm[L_E + TN - 1] = 0.0; sm[L_TAU + TN - 1] = 0.0; }
     __syncthreads();
@@ -608,7 +632,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
           case 6: trd_block_dots<6>(Z, vb, sp, p, q, wp, l); break;
           default: trd_block_dots<7>(Z, vb, sp, p, q, wp, l); break;
         }
-        __syncthreads();
+        lds_barrier();
         switch ((k0 + 1) >> 5) {
           case 0: trd_block_update<0>(Z, vb, sp, tau4, p, q); break;
           case 1: trd_block_update<1>(Z, vb, sp, tau4, p, q); break;
@@ -622,7 +646,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
         par ^= 1;
       }
       block_store(buf ^ 1, nx);
-      __syncthreads();
+      lds_barrier();
     }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {

@@ -16,9 +16,13 @@ for batch in [int(a) for a in sys.argv[1:]] or [1, 28, 112, 224, 256, 280, 512]:
     G = torch.from_numpy(np.stack([Gs[i % len(Gs)] for i in range(batch)])).cuda()
     ms = C.c_double()
     done = (C.c_int * batch)()
-    clk = torch.zeros(batch, 8, dtype=torch.int64, device="cuda")
+    clk = torch.zeros(batch, 16, dtype=torch.int64, device="cuda")
     _lib.check(fn(ptr(G), batch, 5, C.byref(ms), done, ptr(clk), stream_ptr()))
     c = clk.cpu().numpy().astype(np.float64)
     ph = np.diff(c[:, :6], axis=1).mean(axis=0) * 1e-2  # 100 MHz ticks -> us
     print(f"batch {batch:4d}: {ms.value:8.3f} ms per solve   ({sum(done)} of {batch} certified)   phases us: "
           f"A tridiag {ph[0]:.0f}  B eigenvalues {ph[1]:.0f}  C vectors {ph[2]:.0f}  certificate {ph[3]:.0f}  D back-transform {ph[4]:.0f}", flush=True)
+    if c[:, 8:14].any():
+        st = c[:, 8:14].mean(axis=0)
+        print("      phase A step parts (clock64 ticks, summed over the steps): extract+barrier %.0f | vector+barrier %.0f | symv+reduce %.0f | "
+              "barrier %.0f | w+barrier %.0f | update %.0f" % tuple(st), flush=True)
