@@ -152,3 +152,27 @@ def test_frozen_main_sketches_are_never_observed():
             assert la == lb and da == db and np.array_equal(Ba, Bb) and np.array_equal(sa, sb), (kind, t)
         total += Frozen.frozen_rotations
     assert total > 500  # the rule did skip a substantial share of the MAIN rotations
+
+
+def test_query_discard_rule_is_below_the_sketch_guarantee():
+    """The specification zeroes query rows whose shrunk energy is <= 1e-10 lam_0 (as a rotation does).  The rule was added
+    when the device and the specification met (round 2); its justification is independent of any implementation: what
+    it removes from B^T B is at most l * 1e-10 * lam_0 in norm, ten orders of magnitude below the Frequent-Directions
+    guarantee |A_W^T A_W - B^T B| <= |A_W|_F^2 / l that defines the sketch, and below what an SVD of the stacked rows
+    resolves for those rows (sigma to eps * sigma_1, i.e. the energy of such a row to a relative 1e-6 at best)."""
+    from oracle import swfd_oracle as so
+
+    rng = np.random.default_rng(21)
+    for N, d, ell in [(200, 24, 8), (300, 40, 16)]:
+        X = rng.standard_normal((2 * N + 37, d)) * np.logspace(0, -7, d)   # graded columns: tiny trailing directions
+        sk = so.SeqBasedSWFD(N=N, R=float((X ** 2).sum(1).max()), d=d, sketch_dim=ell)
+        sk.fit(X)
+        B_rule = sk.get()[0]
+        M = sk.stacked()
+        s2, Vt, lam0, _ = so._shrink(M, ell)
+        B_free = np.zeros_like(B_rule)
+        B_free[: len(s2)] = np.sqrt(s2)[:, None] * Vt                       # the same query without the rule
+        delta = np.linalg.norm(B_rule.T @ B_rule - B_free.T @ B_free, 2)
+        AW = X[-N:]
+        assert delta <= ell * 1e-10 * lam0
+        assert delta <= 1e-8 * (np.linalg.norm(AW, "fro") ** 2 / ell)
