@@ -1313,8 +1313,7 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->trd) {
       if (!p->direct) { set_error("eig_plan_run_inplace: the direct solver needs the caller to fill eig_plan_input"); return MUSED_ERR_STATE; }
-      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st, nullptr, nullptr, nullptr, nullptr, nullptr,
-                               rec ? p->work : nullptr);
+      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st, nullptr, rec ? p->work : nullptr);
       if (rc) return rc;
       if (rec) {  // the events of a direct-solver plan bracket the direct solver alone (the Jacobi behind it only sees rejects)
         MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));

@@ -88,8 +88,7 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t strea
 // trd.hip: direct solver for order 256, top 128 eigenpairs (tridiagonalisation + multisection + twisted factorisation)
 size_t trd_workspace_doubles(int batch);
 int trd_prepare();
-int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d = nullptr,
-              double* dbg_e = nullptr, double* dbg_lam = nullptr, double* dbg_res = nullptr, long long* dbg_clk = nullptr,
+int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, long long* dbg_clk = nullptr,
               unsigned long long* work = nullptr);
 
 }  // namespace mused

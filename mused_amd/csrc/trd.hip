@@ -29,17 +29,11 @@ namespace mused {
 
 constexpr int TN = 256, TM = 128, TNT = 512;
 // LDS map (doubles): persistent part, then a scratch region reused by the phases
-constexpr int L_D = 0, L_E = 256, L_DD2 = 512 /* double2[256] = {d_i, e_{i-1}^2} */, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280,
-              L_MISC = 1536 /* 16 scalars + [32][4] exchange */, L_S = 1728;
-constexpr int L_TOTAL = L_S + 16384;  // 17,984 doubles = 143,872 bytes
+constexpr int L_D = 0, L_E = 256, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280, L_MISC = 1536, L_S = 1728;
 // phase A scratch
 constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][256] */, A_CP = 1792 /* [2][256] */, A_RED = 2304 /* [8] */;
-// phase C scratch
-constexpr int C_QP = 0 /* [256][32] */, C_QM = 8192;
 // phase D scratch
 constexpr int D_VB = 0 /* [2][16][256] */, D_SP = 8192 /* [2][2][32][26] */;
-// misc slots
-constexpr int M_GL = 0, M_GU = 1, M_PIV = 2, M_TN = 3;
 
 __host__ __device__ constexpr int tidx(int a, int b) { return a * (a + 1) / 2 + b; }
 
@@ -309,21 +303,291 @@ __device__ __forceinline__ void trd_block_update(double (&Z)[16][4], const doubl
   }
 }
 
+// ---- workspace per matrix (doubles) --------------------------------------------------------------------------------
+constexpr long W_HS = 0;                        // 256 x 256 Householder vectors (row k = v_k)
+constexpr long W_ZG = W_HS + (long)TN * TN;     // 256 x 128 eigenvectors of T, unnormalised ([i][c])
+constexpr long W_PV = W_ZG + (long)TN * TM;     // forward pivots [256][128], then backward pivots [256][128]
+constexpr long W_TG = W_PV + 2l * TN * TM;      // d[256], e[256], tau[256]
+constexpr long W_LG = W_TG + 3 * TN;            // lam[128], 1 / |z| [128], residual / |T| [128]
+constexpr long W_MI = W_LG + 3 * TM;            // {|T|, pivmin, bad flag (int), ...}
+constexpr long W_PER = W_MI + 16;
+
 struct TrdDebug {
-  double* d;    // batch x 256
-  double* e;    // batch x 256
-  double* lam;  // batch x 128
-  double* res;  // batch x 128: twisted-factorisation residual / |T|
-  long long* clk;  // batch x 16: wall_clock64() (100 MHz) at the phase boundaries [0..5]; TRD_STEP_PROFILE: cycles per step part [8..13]
+  long long* clk;            // TRD_STEP_PROFILE: batch x 16, cycles per part of a phase-A step in [8 .. 13]
   unsigned long long* work;  // profiling: += 1 per matrix this launch solved (not skipped, not rejected)
 };
 
-__global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
-                                                     int* __restrict__ done, double* __restrict__ Hs_all,
-                                                     double* __restrict__ Zg_all, TrdDebug dbg) {
+// ================= kernel A: tridiagonalisation (one workgroup = one CU per matrix) =================
+__global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
+                                                       double* __restrict__ ws, TrdDebug dbg) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
-  if (rep && rep[bm] != bm) {  // duplicate of another matrix / frozen sketch: nothing to solve (the Jacobi skips it too)
+  if (rep && rep[bm] != bm) return;  // duplicate of another matrix / frozen sketch: nothing to solve
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int wp = w >> 2, wq = w & 3, lp = l >> 3, lq = l & 7;
+  const int p = wp * 8 + lp, q = wq * 8 + lq;
+  const double* G = Gc + (long)bm * TN * TN;
+  double* wsm = ws + (long)bm * W_PER;
+  double* Hs = wsm + W_HS;
+  double* S = sm + L_S;
+  double A[2][36];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        const int i = p + 16 * u + 32 * a, j = q + 32 * b;
+        A[u][tidx(a, b)] = G[(long)j * TN + i] * (a == b ? 0.5 : 1.0);
+      }
+  for (int i = t; i < 768; i += TNT) S[A_XS + i] = 0.0;
+  __syncthreads();
+  long long prof[6] = {0, 0, 0, 0, 0, 0};
+#define TRD_RUN(KV)                                                                           \
+  for (int kk_ = 0; kk_ < 32; ++kk_) {                                                        \
+    const int k_ = 32 * (KV) + kk_;                                                           \
+    if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs, prof);                     \
+  }
+  TRD_RUN(0) TRD_RUN(1) TRD_RUN(2) TRD_RUN(3) TRD_RUN(4) TRD_RUN(5) TRD_RUN(6) TRD_RUN(7)
+#undef TRD_RUN
+#ifdef TRD_STEP_PROFILE
+  if (dbg.clk && t == 0)
+    for (int i = 0; i < 6; ++i) dbg.clk[(long)bm * 16 + 8 + i] = prof[i];
+#endif
+  (void)prof;
+  if (p == 15 && q == 31) sm[L_D + TN - 1] = 2.0 * A[1][tidx(7, 7)];
+  if (t == 0) { sm[L_E + TN - 1] = 0.0; sm[L_TAU + TN - 1] = 0.0; }
+  __syncthreads();
+  if (t < TN) {
+    wsm[W_TG + t] = sm[L_D + t];
+    wsm[W_TG + TN + t] = sm[L_E + t];
+    wsm[W_TG + 2 * TN + t] = sm[L_TAU + t];
+  }
+}
+
+// ================= kernel B: the TM largest eigenvalues of T, 32 per workgroup (4 workgroups per matrix) =================
+// 128 threads: Sturm counts at 128 points (7 bits for every eigenvalue), then 20 passes of 5-section by the 4 lanes of a quad.
+__global__ __launch_bounds__(128) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) double2 dd2[TN];
+  __shared__ double part[6];
+  __shared__ double scal[4];
+  __shared__ int cnts[128];
+  const int bm = blockIdx.x >> 2, cq = blockIdx.x & 3;
+  if (rep && rep[bm] != bm) return;
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  double* wsm = ws + (long)bm * W_PER;
+  const double* dg = wsm + W_TG;
+  const double* eg = wsm + W_TG + TN;
+  double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308, e2m = 0.0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = t + 128 * h;
+    const double di = dg[i], em = i > 0 ? eg[i - 1] : 0.0, ep = eg[i];
+    dd2[i] = make_double2(di, em * em);
+    const double rad = fabs(em) + fabs(ep);
+    lo = fmin(lo, di - rad);
+    hi = fmax(hi, di + rad);
+    e2m = fmax(e2m, ep * ep);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, o));
+    hi = fmax(hi, __shfl_xor(hi, o));
+    e2m = fmax(e2m, __shfl_xor(e2m, o));
+  }
+  if (l == 0) { part[3 * w] = lo; part[3 * w + 1] = hi; part[3 * w + 2] = e2m; }
+  __syncthreads();
+  if (t == 0) {
+    lo = fmin(part[0], part[3]); hi = fmax(part[1], part[4]); e2m = fmax(part[2], part[5]);
+    const double tn = fmax(fabs(lo), fabs(hi));
+    const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
+    scal[0] = lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv;
+    scal[1] = hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv;
+    scal[2] = piv;
+    scal[3] = tn;
+    if (cq == 0) {
+      wsm[W_MI] = tn;
+      wsm[W_MI + 1] = piv;
+      reinterpret_cast<int*>(wsm + W_MI + 2)[0] = 0;  // bad flag (kernel C raises it)
+    }
+  }
+  __syncthreads();
+  const double gl = scal[0], gu = scal[1], pivmin = scal[2];
+  const double h0 = (gu - gl) * (1.0 / 129.0);
+  cnts[t] = trd_sturm(dd2, fma(h0, (double)(t + 1), gl), pivmin);
+  __syncthreads();
+  const int r = cq * 32 + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
+  int first = 0;  // smallest point index whose count exceeds jidx (128: none) -- counts are non-decreasing
+  for (int step = 64; step > 0; step >>= 1)
+    if (first + step <= 128 && cnts[first + step - 1] <= jidx) first += step;
+  if (first < 128 && cnts[first] <= jidx) first += 1;
+  lo = first == 0 ? gl : fma(h0, (double)first, gl);
+  hi = first >= 128 ? gu : fma(h0, (double)(first + 1), gl);
+  for (int it = 0; it < 20; ++it) {  // 5^20 > 2^46
+    const double h = (hi - lo) * 0.2;
+    const double x = fma(h, (double)(s + 1), lo);
+    const int above = trd_sturm(dd2, x, pivmin) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
+    int nf = above;
+    nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR1, 0xf, 0xf, false);
+    nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR2, 0xf, 0xf, false);
+    const double nlo = fma(h, (double)nf, lo);
+    hi = (nf == 4) ? hi : fma(h, (double)(nf + 1), lo);
+    lo = nlo;
+  }
+  if (s == 0) wsm[W_LG + r] = 0.5 * (lo + hi);
+}
+
+// ================= kernel C: eigenvectors of T by twisted factorisation, 32 per workgroup =================
+// Two waves: wave 0 runs the forward pivots and the part of each vector above its twist index, wave 1 the backward pivots
+// and the part below (two dependent chains of 255 divisions side by side); lane c < 32 of either wave = vector cq * 32 + c.
+// The pivot sequences live in global scratch ([i][vector]: a wave's store / load of one i is one 256-byte segment), every
+// stretch of a dependent chain is preceded by its batch of loads: the kernel is latency bound and small (128 threads, 7 KB
+// of LDS), so several of its workgroups share a CU.
+__global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) double2 dd2[TN];
+  __shared__ double es[TN];
+  __shared__ double xch[32 * 4];
+  const int bm = blockIdx.x >> 2, cq = blockIdx.x & 3;
+  if (rep && rep[bm] != bm) return;
+  const int t = threadIdx.x, role = t >> 6, l = t & 63;
+  double* wsm = ws + (long)bm * W_PER;
+  double* Zg = wsm + W_ZG;
+  double* qp = wsm + W_PV;
+  double* qm = wsm + W_PV + (long)TN * TM;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = t + 128 * h;
+    const double em = i > 0 ? wsm[W_TG + TN + i - 1] : 0.0;
+    dd2[i] = make_double2(wsm[W_TG + i], em * em);
+    es[i] = wsm[W_TG + TN + i];
+  }
+  __syncthreads();
+  const double tnorm = wsm[W_MI], pivmin = wsm[W_MI + 1];
+  const double lam0 = wsm[W_LG], lamcut = wsm[W_LG + TM - 1];
+  const bool act = l < 32;
+  const int cl = l & 31, c = cq * 32 + cl;
+  const double lam = wsm[W_LG + c];
+  auto guard = [&](double v) -> double { return fabs(v) < pivmin ? -pivmin : v; };
+  if (act) {
+    if (role == 0) {
+      double qv = dd2[0].x - lam;
+      qp[c] = qv;
+      for (int i0 = 1; i0 < TN; i0 += 5) {  // 255 = 51 x 5
+        double2 de[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) de[j] = dd2[i0 + j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          qv = fma(-de[j].y, trd_rcp(guard(qv)), de[j].x - lam);
+          qp[(long)(i0 + j) * TM + c] = qv;
+        }
+      }
+    } else {
+      double qv = dd2[TN - 1].x - lam;
+      qm[(long)(TN - 1) * TM + c] = qv;
+      for (int i0 = TN - 2; i0 >= 0; i0 -= 5) {  // i0, i0 - 1, .. i0 - 4: 254 .. 0
+        double dx[5], e2[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          dx[j] = dd2[i0 - j].x - lam;
+          e2[j] = dd2[i0 - j + 1].y;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          qv = fma(-e2[j], trd_rcp(guard(qv)), dx[j]);
+          qm[(long)(i0 - j) * TM + c] = qv;
+        }
+      }
+    }
+  }
+  __syncthreads();  // (drains the stores: the other wave reads them)
+  if (act) {  // gamma_i = qp_i + qm_i - (d_i - lam): each role scans one half, ties to the smaller index
+    const int i0 = role * (TN / 2);
+    double best = 1.7976931348623157e308;
+    int kt = i0;
+    for (int ib = i0; ib < i0 + TN / 2; ib += 16) {
+      double a[16], b[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        a[j] = qp[(long)(ib + j) * TM + c];
+        b[j] = qm[(long)(ib + j) * TM + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double g = fabs((a[j] + b[j]) - (dd2[ib + j].x - lam));
+        if (g < best) { best = g; kt = ib + j; }
+      }
+    }
+    xch[cl * 4 + role] = best;
+    xch[cl * 4 + 2 + role] = (double)kt;
+  }
+  __syncthreads();
+  int kt = 0;
+  double gbest = 0.0;
+  if (act) {
+    const double b0 = xch[cl * 4], b1 = xch[cl * 4 + 1];
+    const bool up = !(b1 < b0);  // ties: the smaller index (first half)
+    gbest = up ? b0 : b1;
+    kt = (int)(up ? xch[cl * 4 + 2] : xch[cl * 4 + 3]);
+  }
+  __syncthreads();  // xch is read: it may be rewritten
+  if (act) {
+    double ss = 0.0, zc = 1.0;
+    if (role == 0) {
+      Zg[(long)kt * TM + c] = 1.0;
+      for (int ib = kt - 1; ib >= 0; ib -= 8) {
+        double qq[8], ee[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = ib - j;
+          qq[j] = i >= 0 ? qp[(long)i * TM + c] : 1.0;
+          ee[j] = i >= 0 ? es[i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
+          if (ib - j >= 0) Zg[(long)(ib - j) * TM + c] = zc;
+          ss = fma(zc, zc, ss);
+        }
+      }
+    } else {
+      for (int ib = kt + 1; ib < TN; ib += 8) {
+        double qq[8], ee[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = ib + j;
+          qq[j] = i < TN ? qm[(long)i * TM + c] : 1.0;
+          ee[j] = i < TN ? es[i - 1] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
+          if (ib + j < TN) Zg[(long)(ib + j) * TM + c] = zc;
+          ss = fma(zc, zc, ss);
+        }
+      }
+    }
+    xch[cl * 4 + role] = ss;
+  }
+  __syncthreads();
+  if (act && role == 0) {
+    const double ss = 1.0 + xch[cl * 4] + xch[cl * 4 + 1];
+    const double zs = 1.0 / sqrt(ss);
+    wsm[W_LG + TM + c] = zs;
+    const double res = gbest * zs / (tnorm > 0.0 ? tnorm : 1.0);
+    wsm[W_LG + 2 * TM + c] = res;
+    const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
+    const bool sig = lam > 0.0 && (lam - lamcut) > sigtol;
+    if (sig && !(ss < 1e300 && res <= 1e-11)) atomicOr(reinterpret_cast<int*>(wsm + W_MI + 2), 1);
+  }
+}
+
+// ================= kernel D: certificate, then V = Q Z, columns written as lam_j v_j =================
+__global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
+                                                       int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int bm = blockIdx.x;
+  if (rep && rep[bm] != bm) {  // (the Jacobi skips it too)
     if (threadIdx.x == 0) done[bm] = 1;
     return;
   }
@@ -331,354 +595,132 @@ __global__ __launch_bounds__(TNT, 1) void trd_kernel(double* __restrict__ Gc, co
   const int wp = w >> 2, wq = w & 3, lp = l >> 3, lq = l & 7;
   const int p = wp * 8 + lp, q = wq * 8 + lq;
   double* G = Gc + (long)bm * TN * TN;
-  double* Hs = Hs_all + (long)bm * TN * TN;
-  double* Zg = Zg_all + (long)bm * TN * TM;
+  double* wsm = ws + (long)bm * W_PER;
+  const double* Hs = wsm + W_HS;
+  const double* Zg = wsm + W_ZG;
   double* S = sm + L_S;
-
-  auto stamp = [&](int i) { if (dbg.clk && t == 0) dbg.clk[(long)bm * 16 + i] = wall_clock64(); };
-  stamp(0);
-  // ================= phase A: tridiagonalisation =================
-  {
-    double A[2][36];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-          const int i = p + 16 * u + 32 * a, j = q + 32 * b;
-          A[u][tidx(a, b)] = G[(long)j * TN + i] * (a == b ? 0.5 : 1.0);
-        }
-    for (int i = t; i < 768; i += TNT) S[A_XS + i] = 0.0;
-    __syncthreads();
-    long long prof[6] = {0, 0, 0, 0, 0, 0};
-#define TRD_RUN(KV)                                                                           \
-    for (int kk_ = 0; kk_ < 32; ++kk_) {                                                      \
-      const int k_ = 32 * (KV) + kk_;                                                         \
-      if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs, prof);                   \
-    }
-    TRD_RUN(0) TRD_RUN(1) TRD_RUN(2) TRD_RUN(3) TRD_RUN(4) TRD_RUN(5) TRD_RUN(6) TRD_RUN(7)
-#undef TRD_RUN
-#ifdef TRD_STEP_PROFILE
-    if (dbg.clk && t == 0)
-      for (int i = 0; i < 6; ++i) dbg.clk[(long)bm * 16 + 8 + i] = prof[i];
-#endif
-    if (p == 15 && q == 31) sm[L_D + TN - 1] = 2.0 * A[1][tidx(7, 7)];
-    if (t == 0) { sm[L_E + TN - 1] = 0.0; sm[L_TAU + TN - 1] = 0.0; }
-    __syncthreads();
+  int* badflag = reinterpret_cast<int*>(sm + L_MISC + 8);
+  if (t < TN) sm[L_TAU + t] = wsm[W_TG + 2 * TN + t];
+  if (t < TM) {
+    sm[L_LAM + t] = wsm[W_LG + t];
+    sm[L_ZS + t] = wsm[W_LG + TM + t];
   }
-
-  stamp(1);
-  // ================= phase B: the TM largest eigenvalues of T =================
-  double2* dd2 = reinterpret_cast<double2*>(sm + L_DD2);
-  {
-    if (t < TN) {
-      const double em = t > 0 ? sm[L_E + t - 1] : 0.0, ep = sm[L_E + t];
-      dd2[t] = make_double2(sm[L_D + t], em * em);
-      const double rad = fabs(em) + fabs(ep);
-      double lo = sm[L_D + t] - rad, hi = sm[L_D + t] + rad, e2m = ep * ep;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, o));
-        hi = fmax(hi, __shfl_xor(hi, o));
-        e2m = fmax(e2m, __shfl_xor(e2m, o));
-      }
-      if (l == 0) { S[3 * w] = lo; S[3 * w + 1] = hi; S[3 * w + 2] = e2m; }
-    }
-    __syncthreads();
-    if (t == 0) {
-      double lo = S[0], hi = S[1], e2m = S[2];
-      for (int ww = 1; ww < 4; ++ww) { lo = fmin(lo, S[3 * ww]); hi = fmax(hi, S[3 * ww + 1]); e2m = fmax(e2m, S[3 * ww + 2]); }
-      const double tn = fmax(fabs(lo), fabs(hi));
-      const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
-      sm[L_MISC + M_GL] = lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv;
-      sm[L_MISC + M_GU] = hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv;
-      sm[L_MISC + M_PIV] = piv;
-      sm[L_MISC + M_TN] = tn;
-    }
-    __syncthreads();
-    const double pivmin = sm[L_MISC + M_PIV];
-    const double gl = sm[L_MISC + M_GL], gu = sm[L_MISC + M_GU];
-    // pass 0: counts at 512 equispaced points locate every eigenvalue to 1 / 513 of the Gershgorin interval
-    int* cnts = reinterpret_cast<int*>(S + 16);
-    const double h0 = (gu - gl) * (1.0 / 513.0);
-    cnts[t] = trd_sturm(dd2, fma(h0, (double)(t + 1), gl), pivmin);
-    __syncthreads();
-    const int r = t >> 2, s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
-    int first = 0;  // smallest point index whose count exceeds jidx (512: none) -- counts are non-decreasing
-    for (int step = 256; step > 0; step >>= 1)
-      if (first + step <= 512 && cnts[first + step - 1] <= jidx) first += step;
-    if (first < 512 && cnts[first] <= jidx) first += 1;
-    double lo = first == 0 ? gl : fma(h0, (double)first, gl);
-    double hi = first >= 512 ? gu : fma(h0, (double)(first + 1), gl);
-    // 19 passes of 5-section by the 4 lanes of a quad: 5^19 > 2^44
-    for (int it = 0; it < 19; ++it) {
-      const double h = (hi - lo) * 0.2;
-      const double x = fma(h, (double)(s + 1), lo);
-      const int above = trd_sturm(dd2, x, pivmin) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
-      int nf = above;
-      nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR1, 0xf, 0xf, false);
-      nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR2, 0xf, 0xf, false);
-      const double nlo = fma(h, (double)nf, lo);
-      hi = (nf == 4) ? hi : fma(h, (double)(nf + 1), lo);
-      lo = nlo;
-    }
-    if (s == 0) sm[L_LAM + r] = 0.5 * (lo + hi);
-    __syncthreads();
-  }
-  stamp(2);
-  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1], tnorm = sm[L_MISC + M_TN];
+  if (t == 0) *badflag = reinterpret_cast<const int*>(wsm + W_MI + 2)[0];
+  __syncthreads();
+  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1];
   const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
   auto significant = [&](int c) -> bool { const double lc = sm[L_LAM + c]; return lc > 0.0 && (lc - lamcut) > sigtol; };
-  int* badflag = reinterpret_cast<int*>(sm + L_MISC + 8);
-  if (t == 0) *badflag = 0;
-
-  // ================= phase C: eigenvectors of T by twisted factorisation, 32 at a time =================
+  // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
   {
-    const double pivmin = sm[L_MISC + M_PIV];
-    double* qp = S + C_QP;
-    double* qm = S + C_QM;
-    auto guard = [&](double v) -> double { return fabs(v) < pivmin ? -pivmin : v; };
-    double* xch = sm + L_MISC + 16;  // [32][4] exchange between the two lanes of a vector (scratch S is full)
-    for (int rd = 0; rd < TM / 32; ++rd) {
-      __syncthreads();  // the previous round's pivot arrays are free (and *badflag is initialised)
-      // Two lanes per vector, in DIFFERENT waves (the two roles are divergent code: inside one wave they would run one
-      // after the other): waves 0-3 run the forward pivots and the part of the vector above the twist index (role 0),
-      // waves 4-7 the backward pivots and the part below (role 1) -- two dependent chains of 255 divisions side by side
-      // instead of one of 1,020.  8 vectors per wave (every 8th lane).
-      const bool act = (t & 7) == 0;
-      const int role = w >> 2, cl = (w & 3) * 8 + (l >> 3), c = rd * 32 + cl;
-      const double lam = sm[L_LAM + c];
-      // (the loops below fetch a batch of operands into registers before each stretch of the dependent chain: only 8 lanes
-      // of a wave work here, what limits them is latency, and a load issued inside the chain would sit in front of it)
-      if (act) {
-        if (role == 0) {
-          double qv = dd2[0].x - lam;
-          qp[cl] = qv;
-          for (int i0 = 1; i0 < TN; i0 += 5) {  // 255 = 51 x 5
-            double2 de[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) de[j] = dd2[i0 + j];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              qv = fma(-de[j].y, trd_rcp(guard(qv)), de[j].x - lam);
-              qp[(i0 + j) * 32 + cl] = qv;
-            }
-          }
-        } else {
-          double qv = dd2[TN - 1].x - lam;
-          qm[(TN - 1) * 32 + cl] = qv;
-          for (int i0 = TN - 2; i0 >= 0; i0 -= 5) {  // i0, i0 - 1, .. i0 - 4: 254 .. 0
-            double dx[5], e2[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              dx[j] = dd2[i0 - j].x - lam;
-              e2[j] = dd2[i0 - j + 1].y;
-            }
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              qv = fma(-e2[j], trd_rcp(guard(qv)), dx[j]);
-              qm[(i0 - j) * 32 + cl] = qv;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (act) {  // gamma_i = qp_i + qm_i - (d_i - lam): each role scans one half, ties to the smaller index
-        const int i0 = role * (TN / 2);
-        double best = 1.7976931348623157e308;
-        int kt = i0;
-        for (int ib = i0; ib < i0 + TN / 2; ib += 8) {
-          double g[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) g[j] = fabs((qp[(ib + j) * 32 + cl] + qm[(ib + j) * 32 + cl]) - (dd2[ib + j].x - lam));
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (g[j] < best) { best = g[j]; kt = ib + j; }
-        }
-        xch[cl * 4 + role] = best;
-        xch[cl * 4 + 2 + role] = (double)kt;
-      }
-      __syncthreads();
-      int kt = 0;
-      double gbest = 0.0;
-      if (act) {
-        const double b0 = xch[cl * 4], b1 = xch[cl * 4 + 1];
-        const bool up = !(b1 < b0);  // ties: the smaller index (first half)
-        gbest = up ? b0 : b1;
-        kt = (int)(up ? xch[cl * 4 + 2] : xch[cl * 4 + 3]);
-      }
-      __syncthreads();  // xch is read: it may be rewritten
-      if (act) {
-        double ss = 0.0, zc = 1.0;
-        if (role == 0) {
-          Zg[(long)kt * TM + c] = 1.0;
-          for (int ib = kt - 1; ib >= 0; ib -= 4) {
-            double qq[4], ee[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int i = ib - j;
-              qq[j] = i >= 0 ? qp[i * 32 + cl] : 1.0;
-              ee[j] = i >= 0 ? sm[L_E + i] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
-              if (ib - j >= 0) Zg[(long)(ib - j) * TM + c] = zc;
-              ss = fma(zc, zc, ss);
-            }
-          }
-        } else {
-          for (int ib = kt + 1; ib < TN; ib += 4) {
-            double qq[4], ee[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int i = ib + j;
-              qq[j] = i < TN ? qm[i * 32 + cl] : 1.0;
-              ee[j] = i < TN ? sm[L_E + i - 1] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
-              if (ib + j < TN) Zg[(long)(ib + j) * TM + c] = zc;
-              ss = fma(zc, zc, ss);
-            }
-          }
-        }
-        xch[cl * 4 + role] = ss;
-      }
-      __syncthreads();
-      if (act && role == 0) {
-        const double ss = 1.0 + xch[cl * 4] + xch[cl * 4 + 1];
-        const double zs = 1.0 / sqrt(ss);
-        sm[L_ZS + c] = zs;
-        const double res = gbest * zs / (tnorm > 0.0 ? tnorm : 1.0);
-        if (dbg.res) dbg.res[(long)bm * TM + c] = res;
-        if (significant(c) && !(ss < 1e300 && res <= 1e-11)) atomicOr(badflag, 1);
-      }
+    const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
+    if (c2 < TM && significant(c) && significant(c2)) {
+      double dotv = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
+      if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= 1e-8)) atomicOr(badflag, 2);
     }
-    __syncthreads();
-    stamp(3);
-    // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
-    {
-      const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
-      if (c2 < TM && significant(c) && significant(c2)) {
-        double dotv = 0.0;
-        for (int i = 0; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
-        if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= 1e-8)) atomicOr(badflag, 2);
-      }
-      if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5) &&
-          (sm[L_LAM + c] - sm[L_LAM + c + 5]) <= 1e-7 * lam0)
-        atomicOr(badflag, 4);
-    }
-    __syncthreads();
+    if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5) &&
+        (sm[L_LAM + c] - sm[L_LAM + c + 5]) <= 1e-7 * lam0)
+      atomicOr(badflag, 4);
   }
-  stamp(4);
-  if (dbg.d) {
-    if (t < TN) { dbg.d[(long)bm * TN + t] = sm[L_D + t]; dbg.e[(long)bm * TN + t] = sm[L_E + t]; }
-    if (t < TM) dbg.lam[(long)bm * TM + t] = sm[L_LAM + t];
-  }
+  __syncthreads();
   if (*badflag) {  // leave G as it is: the Jacobi solver takes this matrix
     if (t == 0) done[bm] = 0;
     return;
   }
-
-  // ================= phase D: V = Q Z, columns written as lam_j v_j =================
-  {
-    double Z[16][4];
+  double Z[16][4];
 #pragma unroll
-    for (int a = 0; a < 16; ++a)
+  for (int a = 0; a < 16; ++a)
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) Z[a][cb] = Zg[(long)(p + 16 * a) * TM + q + 32 * cb] * sm[L_ZS + q + 32 * cb];
-    __syncthreads();  // scratch region: pivot arrays -> reflector blocks / partial-sum buffers
-    // Reflectors are staged in LDS in blocks of 16 (the next block travels from global memory into registers while the
-    // current one is applied), so that a step costs one barrier: s = v^T Z reduced over the thread rows, then Z -= tau v s^T.
-    constexpr int DBK = 16;
-    double* vblk = S + D_VB;   // [2][DBK][256]
-    double* spb = S + D_SP;    // [2][2][32][D_SPQ]
-    auto block_fetch = [&](int kb, double (&nx)[8]) {
+    for (int cb = 0; cb < 4; ++cb) Z[a][cb] = Zg[(long)(p + 16 * a) * TM + q + 32 * cb] * sm[L_ZS + q + 32 * cb];
+  // Reflectors are staged in LDS in blocks of 16 (the next block travels from global memory into registers while the
+  // current one is applied), four are applied per barrier (trd_block_dots / trd_block_update).
+  constexpr int DBK = 16;
+  double* vblk = S + D_VB;   // [2][DBK][256]
+  double* spb = S + D_SP;    // [2][2][32][D_SPQ]
+  auto block_fetch = [&](int kb, double (&nx)[8]) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int idx = t + TNT * m, kr = DBK * kb + (idx >> 8);
-        nx[m] = (kb >= 0 && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
+    for (int m = 0; m < 8; ++m) {
+      const int idx = t + TNT * m, kr = DBK * kb + (idx >> 8);
+      nx[m] = (kb >= 0 && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
+    }
+  };
+  auto block_store = [&](int buf, const double (&nx)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) vblk[buf * (DBK * 256) + t + TNT * m] = nx[m];
+  };
+  double nx[8];
+  const int kb_top = (TN - 3) / DBK;
+  block_fetch(kb_top, nx);
+  block_store(0, nx);
+  __syncthreads();
+  int par = 0;
+  for (int kb = kb_top; kb >= 0; --kb) {
+    const int buf = (kb_top - kb) & 1;
+    block_fetch(kb - 1, nx);
+    for (int k4 = DBK / 4 - 1; k4 >= 0; --k4) {
+      const int k0 = DBK * kb + 4 * k4;  // reflectors k0 .. k0 + 3 (beyond TN - 3: zero vectors, tau = 0)
+      const double* tau4 = sm + L_TAU + k0;
+      if (tau4[0] == 0.0 && tau4[1] == 0.0 && tau4[2] == 0.0 && tau4[3] == 0.0) continue;  // uniform
+      const double* vb = vblk + buf * (DBK * 256) + 4 * k4 * 256;
+      double* sp = spb + par * (2 * 32 * D_SPQ);
+      switch ((k0 + 1) >> 5) {
+        case 0: trd_block_dots<0>(Z, vb, sp, p, q, wp, l); break;
+        case 1: trd_block_dots<1>(Z, vb, sp, p, q, wp, l); break;
+        case 2: trd_block_dots<2>(Z, vb, sp, p, q, wp, l); break;
+        case 3: trd_block_dots<3>(Z, vb, sp, p, q, wp, l); break;
+        case 4: trd_block_dots<4>(Z, vb, sp, p, q, wp, l); break;
+        case 5: trd_block_dots<5>(Z, vb, sp, p, q, wp, l); break;
+        case 6: trd_block_dots<6>(Z, vb, sp, p, q, wp, l); break;
+        default: trd_block_dots<7>(Z, vb, sp, p, q, wp, l); break;
       }
-    };
-    auto block_store = [&](int buf, const double (&nx)[8]) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) vblk[buf * (DBK * 256) + t + TNT * m] = nx[m];
-    };
-    double nx[8];
-    const int kb_top = (TN - 3) / DBK;
-    block_fetch(kb_top, nx);
-    block_store(0, nx);
-    __syncthreads();
-    int par = 0;
-    for (int kb = kb_top; kb >= 0; --kb) {
-      const int buf = (kb_top - kb) & 1;
-      block_fetch(kb - 1, nx);
-      for (int k4 = DBK / 4 - 1; k4 >= 0; --k4) {
-        const int k0 = DBK * kb + 4 * k4;  // reflectors k0 .. k0 + 3 (beyond TN - 3: zero vectors, tau = 0)
-        const double* tau4 = sm + L_TAU + k0;
-        if (tau4[0] == 0.0 && tau4[1] == 0.0 && tau4[2] == 0.0 && tau4[3] == 0.0) continue;  // uniform
-        const double* vb = vblk + buf * (DBK * 256) + 4 * k4 * 256;
-        double* sp = spb + par * (2 * 32 * D_SPQ);
-        switch ((k0 + 1) >> 5) {
-          case 0: trd_block_dots<0>(Z, vb, sp, p, q, wp, l); break;
-          case 1: trd_block_dots<1>(Z, vb, sp, p, q, wp, l); break;
-          case 2: trd_block_dots<2>(Z, vb, sp, p, q, wp, l); break;
-          case 3: trd_block_dots<3>(Z, vb, sp, p, q, wp, l); break;
-          case 4: trd_block_dots<4>(Z, vb, sp, p, q, wp, l); break;
-          case 5: trd_block_dots<5>(Z, vb, sp, p, q, wp, l); break;
-          case 6: trd_block_dots<6>(Z, vb, sp, p, q, wp, l); break;
-          default: trd_block_dots<7>(Z, vb, sp, p, q, wp, l); break;
-        }
-        lds_barrier();
-        switch ((k0 + 1) >> 5) {
-          case 0: trd_block_update<0>(Z, vb, sp, tau4, p, q); break;
-          case 1: trd_block_update<1>(Z, vb, sp, tau4, p, q); break;
-          case 2: trd_block_update<2>(Z, vb, sp, tau4, p, q); break;
-          case 3: trd_block_update<3>(Z, vb, sp, tau4, p, q); break;
-          case 4: trd_block_update<4>(Z, vb, sp, tau4, p, q); break;
-          case 5: trd_block_update<5>(Z, vb, sp, tau4, p, q); break;
-          case 6: trd_block_update<6>(Z, vb, sp, tau4, p, q); break;
-          default: trd_block_update<7>(Z, vb, sp, tau4, p, q); break;
-        }
-        par ^= 1;
-      }
-      block_store(buf ^ 1, nx);
       lds_barrier();
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      const int c = q + 32 * cb;
-      const double lc = sm[L_LAM + c];
-      const double f = lc > 0.0 ? lc : 0.0;
-#pragma unroll
-      for (int a = 0; a < 16; ++a) {
-        G[(long)c * TN + p + 16 * a] = f * Z[a][cb];
-        G[(long)(c + TM) * TN + p + 16 * a] = 0.0;
+      switch ((k0 + 1) >> 5) {
+        case 0: trd_block_update<0>(Z, vb, sp, tau4, p, q); break;
+        case 1: trd_block_update<1>(Z, vb, sp, tau4, p, q); break;
+        case 2: trd_block_update<2>(Z, vb, sp, tau4, p, q); break;
+        case 3: trd_block_update<3>(Z, vb, sp, tau4, p, q); break;
+        case 4: trd_block_update<4>(Z, vb, sp, tau4, p, q); break;
+        case 5: trd_block_update<5>(Z, vb, sp, tau4, p, q); break;
+        case 6: trd_block_update<6>(Z, vb, sp, tau4, p, q); break;
+        default: trd_block_update<7>(Z, vb, sp, tau4, p, q); break;
       }
+      par ^= 1;
     }
-    if (t == 0) {
-      done[bm] = 1;
-      if (dbg.work) atomicAdd(dbg.work, 1ull);
+    block_store(buf ^ 1, nx);
+    lds_barrier();
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int c = q + 32 * cb;
+    const double lc = sm[L_LAM + c];
+    const double f = lc > 0.0 ? lc : 0.0;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      G[(long)c * TN + p + 16 * a] = f * Z[a][cb];
+      G[(long)(c + TM) * TN + p + 16 * a] = 0.0;
     }
   }
-  stamp(5);
+  if (t == 0) {
+    done[bm] = 1;
+    if (dbg.work) atomicAdd(dbg.work, 1ull);
+  }
 }
 
 }  // namespace mused
 
 namespace mused {
 
-// Workspace per matrix: reflectors (256 x 256) + tridiagonal eigenvectors (256 x 128), doubles
-size_t trd_workspace_doubles(int batch) { return (size_t)batch * ((size_t)TN * TN + (size_t)TN * TM); }
+size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; }
+
+constexpr int L_A_TOTAL = L_S + 2312;            // kernel A: persistent part + its scratch
+constexpr int L_D_TOTAL = L_S + D_SP + 2 * 2 * 32 * D_SPQ;  // kernel D: reflector blocks + partial sums
 
 int trd_prepare() {
   static std::once_flag once;
   static hipError_t rc = hipSuccess;
   std::call_once(once, [] {
-    rc = hipFuncSetAttribute((const void*)trd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_TOTAL));
+    rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_D_TOTAL));
   });
   MUSED_CHECK_HIP(rc);
   return MUSED_OK;
@@ -686,15 +728,29 @@ int trd_prepare() {
 
 // Solves the matrices of Gc (batch x 256 x 256, symmetric) in place: done[b] = 1 -> columns 0 .. 127 of matrix b hold
 // lam_j v_j for its 128 largest eigenvalues (descending), columns 128 .. 255 zeros; done[b] = 0 -> untouched (certificate
-// failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.
-int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, double* dbg_d, double* dbg_e,
-              double* dbg_lam, double* dbg_res, long long* dbg_clk, unsigned long long* work) {
-  TrdDebug dbg{dbg_d, dbg_e, dbg_lam, dbg_res, dbg_clk, work};
-  double* Hs = ws;
-  double* Zg = ws + (size_t)batch * TN * TN;
-  hipLaunchKernelGGL(trd_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_TOTAL, st, Gc, rep, done, Hs, Zg, dbg);
+// failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.  Four launches on `st`.
+int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, long long* dbg_clk,
+              unsigned long long* work) {
+  TrdDebug dbg{dbg_clk, work};
+  hipLaunchKernelGGL(trd_a_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg);
+  hipLaunchKernelGGL(trd_b_kernel, dim3(4 * batch), dim3(128), 0, st, rep, ws);
+  hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), 0, st, rep, ws);
+  hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_D_TOTAL, st, Gc, rep, done, ws, dbg);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
+}
+
+// test / diagnostic: copy the tridiagonal matrix, the eigenvalues and the residuals of matrix b out of the workspace
+__global__ void trd_export_kernel(const double* __restrict__ ws, double* __restrict__ d, double* __restrict__ e,
+                                  double* __restrict__ lam, double* __restrict__ res) {
+  const int bm = blockIdx.x, t = threadIdx.x;
+  const double* wsm = ws + (long)bm * W_PER;
+  if (d) d[(long)bm * TN + t] = wsm[W_TG + t];
+  if (e) e[(long)bm * TN + t] = wsm[W_TG + TN + t];
+  if (t < TM) {
+    if (lam) lam[(long)bm * TM + t] = wsm[W_LG + t];
+    if (res) res[(long)bm * TM + t] = wsm[W_LG + 2 * TM + t];
+  }
 }
 
 }  // namespace mused
@@ -709,10 +765,12 @@ extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_
   MUSED_REQUIRE(G && batch >= 1 && out_done, "mused_debug_trd: bad arguments");
   int rc = trd_prepare();
   if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
   double* ws = nullptr;
   MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trd_workspace_doubles(batch)));
-  rc = trd_solve(G, batch, nullptr, out_done, ws, (hipStream_t)stream, out_d, out_e, out_lam, out_res);
-  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  rc = trd_solve(G, batch, nullptr, out_done, ws, st);
+  hipLaunchKernelGGL(trd_export_kernel, dim3(batch), dim3(TN), 0, st, ws, out_d, out_e, out_lam, out_res);
+  hipError_t e = hipStreamSynchronize(st);
   (void)hipFree(ws);
   if (rc) return rc;
   MUSED_CHECK_HIP(e);
@@ -740,7 +798,7 @@ extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double
   for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
     MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
     MUSED_CHECK_HIP(hipEventRecord(e0, st));
-    rc = trd_solve(work, batch, nullptr, done, ws, st, nullptr, nullptr, nullptr, nullptr, out_clk);
+    rc = trd_solve(work, batch, nullptr, done, ws, st, out_clk);
     MUSED_CHECK_HIP(hipEventRecord(e1, st));
     MUSED_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -19,9 +19,8 @@ for batch in [int(a) for a in sys.argv[1:]] or [1, 28, 112, 224, 256, 280, 512]:
     clk = torch.zeros(batch, 16, dtype=torch.int64, device="cuda")
     _lib.check(fn(ptr(G), batch, 5, C.byref(ms), done, ptr(clk), stream_ptr()))
     c = clk.cpu().numpy().astype(np.float64)
-    ph = np.diff(c[:, :6], axis=1).mean(axis=0) * 1e-2  # 100 MHz ticks -> us
-    print(f"batch {batch:4d}: {ms.value:8.3f} ms per solve   ({sum(done)} of {batch} certified)   phases us: "
-          f"A tridiag {ph[0]:.0f}  B eigenvalues {ph[1]:.0f}  C vectors {ph[2]:.0f}  certificate {ph[3]:.0f}  D back-transform {ph[4]:.0f}", flush=True)
+    print(f"batch {batch:4d}: {ms.value:8.3f} ms per solve   ({sum(done)} of {batch} certified)   (per-kernel times: rocprofv3 "
+          f"--kernel-trace --stats on this script)", flush=True)
     if c[:, 8:14].any():
         st = c[:, 8:14].mean(axis=0)
         print("      phase A step parts (clock64 ticks, summed over the steps): extract+barrier %.0f | vector+barrier %.0f | symv+reduce %.0f | "
