@@ -278,19 +278,18 @@ __device__ __forceinline__ void trd_block_dots(const double (&Z)[16][4], const d
 template <int KD>
 __device__ __forceinline__ void trd_block_update(double (&Z)[16][4], const double* __restrict__ vb, const double* __restrict__ sp,
                                                  const double* __restrict__ tau4, const int p, const int q) {
-  double sv[24];
   const double* s0 = sp + q * D_SPQ;
   const double* s1 = sp + (32 + q) * D_SPQ;
-#pragma unroll
-  for (int e = 0; e < 22; ++e) sv[e] = s0[e] + s1[e];
+  auto sum2 = [&](int e) -> double { return s0[e] + s1[e]; };  // (the two thread-row halves of the workgroup)
   const double t0 = tau4[0], t1 = tau4[1], t2 = tau4[2], t3 = tau4[3];
+  const double g01 = sum2(16), g02 = sum2(17), g03 = sum2(18), g12 = sum2(19), g13 = sum2(20), g23 = sum2(21);
   double c[4][4];
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
-    c[3][cb] = t3 * sv[12 + cb];
-    c[2][cb] = t2 * fma(-sv[21], c[3][cb], sv[8 + cb]);
-    c[1][cb] = t1 * fma(-sv[20], c[3][cb], fma(-sv[19], c[2][cb], sv[4 + cb]));
-    c[0][cb] = t0 * fma(-sv[18], c[3][cb], fma(-sv[17], c[2][cb], fma(-sv[16], c[1][cb], sv[cb])));
+    c[3][cb] = t3 * sum2(12 + cb);
+    c[2][cb] = t2 * fma(-g23, c[3][cb], sum2(8 + cb));
+    c[1][cb] = t1 * fma(-g13, c[3][cb], fma(-g12, c[2][cb], sum2(4 + cb)));
+    c[0][cb] = t0 * fma(-g03, c[3][cb], fma(-g02, c[2][cb], fma(-g01, c[1][cb], sum2(cb))));
   }
 #pragma unroll
   for (int a = 2 * KD; a < 16; ++a) {
