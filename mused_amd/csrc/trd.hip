@@ -364,23 +364,26 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
   }
 }
 
-// ================= kernel B: the TM largest eigenvalues of T, 32 per workgroup (4 workgroups per matrix) =================
-// 128 threads: Sturm counts at 128 points (7 bits for every eigenvalue), then 20 passes of 5-section by the 4 lanes of a quad.
-__global__ __launch_bounds__(128) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+// ================= kernel B: the TM largest eigenvalues of T, NTB / 4 per workgroup (512 / NTB workgroups per matrix) =========
+// Sturm counts at NTB points first (log2(NTB + 1) bits for every eigenvalue), then passes of 5-section by the 4 lanes of a quad
+// (2.32 bits each).  NTB = 512: one workgroup per matrix, two waves per SIMD (full vector-ALU rate: large batches);
+// NTB = 128: four workgroups per matrix (small batches spread over the CUs they would leave idle).
+template <int NTB>
+__global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+  constexpr int NCH = TNT / NTB, NWV = NTB / 64;
+  constexpr int PASSES = NTB == 512 ? 19 : (NTB == 256 ? 20 : 20);  // 5^19 x 513 > 2^53, 5^20 x 129 > 2^53
   __shared__ __attribute__((aligned(16))) double2 dd2[TN];
-  __shared__ double part[6];
+  __shared__ double part[3 * NWV];
   __shared__ double scal[4];
-  __shared__ int cnts[128];
-  const int bm = blockIdx.x >> 2, cq = blockIdx.x & 3;
+  __shared__ int cnts[NTB];
+  const int bm = blockIdx.x / NCH, cq = blockIdx.x % NCH;
   if (rep && rep[bm] != bm) return;
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   double* wsm = ws + (long)bm * W_PER;
   const double* dg = wsm + W_TG;
   const double* eg = wsm + W_TG + TN;
   double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308, e2m = 0.0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int i = t + 128 * h;
+  for (int i = t; i < TN; i += NTB) {
     const double di = dg[i], em = i > 0 ? eg[i - 1] : 0.0, ep = eg[i];
     dd2[i] = make_double2(di, em * em);
     const double rad = fabs(em) + fabs(ep);
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(128) void trd_b_kernel(const int* __restrict__ rep,
   if (l == 0) { part[3 * w] = lo; part[3 * w + 1] = hi; part[3 * w + 2] = e2m; }
   __syncthreads();
   if (t == 0) {
-    lo = fmin(part[0], part[3]); hi = fmax(part[1], part[4]); e2m = fmax(part[2], part[5]);
+    for (int ww = 1; ww < NWV; ++ww) { lo = fmin(lo, part[3 * ww]); hi = fmax(hi, part[3 * ww + 1]); e2m = fmax(e2m, part[3 * ww + 2]); }
     const double tn = fmax(fabs(lo), fabs(hi));
     const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
     scal[0] = lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv;
@@ -412,17 +415,17 @@ __global__ __launch_bounds__(128) void trd_b_kernel(const int* __restrict__ rep,
   }
   __syncthreads();
   const double gl = scal[0], gu = scal[1], pivmin = scal[2];
-  const double h0 = (gu - gl) * (1.0 / 129.0);
+  const double h0 = (gu - gl) * (1.0 / (double)(NTB + 1));
   cnts[t] = trd_sturm(dd2, fma(h0, (double)(t + 1), gl), pivmin);
   __syncthreads();
-  const int r = cq * 32 + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
-  int first = 0;  // smallest point index whose count exceeds jidx (128: none) -- counts are non-decreasing
-  for (int step = 64; step > 0; step >>= 1)
-    if (first + step <= 128 && cnts[first + step - 1] <= jidx) first += step;
-  if (first < 128 && cnts[first] <= jidx) first += 1;
+  const int r = cq * (NTB / 4) + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
+  int first = 0;  // smallest point index whose count exceeds jidx (NTB: none) -- counts are non-decreasing
+  for (int step = NTB / 2; step > 0; step >>= 1)
+    if (first + step <= NTB && cnts[first + step - 1] <= jidx) first += step;
+  if (first < NTB && cnts[first] <= jidx) first += 1;
   lo = first == 0 ? gl : fma(h0, (double)first, gl);
-  hi = first >= 128 ? gu : fma(h0, (double)(first + 1), gl);
-  for (int it = 0; it < 20; ++it) {  // 5^20 > 2^46
+  hi = first >= NTB ? gu : fma(h0, (double)(first + 1), gl);
+  for (int it = 0; it < PASSES; ++it) {
     const double h = (hi - lo) * 0.2;
     const double x = fma(h, (double)(s + 1), lo);
     const int above = trd_sturm(dd2, x, pivmin) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
@@ -732,7 +735,8 @@ int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipS
               unsigned long long* work) {
   TrdDebug dbg{dbg_clk, work};
   hipLaunchKernelGGL(trd_a_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg);
-  hipLaunchKernelGGL(trd_b_kernel, dim3(4 * batch), dim3(128), 0, st, rep, ws);
+  if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(4 * batch), dim3(128), 0, st, rep, ws);
+  else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws);
   hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), 0, st, rep, ws);
   hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_D_TOTAL, st, Gc, rep, done, ws, dbg);
   MUSED_LAUNCH_CHECK();
