@@ -118,6 +118,17 @@ int mused_adj_to_dense(const unsigned long long* mask, int n, int words, int dty
 int mused_adj_from_dense(const void* dense, int dtype, int n, long ld, int words, unsigned long long* mask,
                          int* nonbinary, void* stream);
 
+/* ---- f3: hopping windows (step_window_ratio > 1, main.py:32) with reuse across consecutive windows --------------------
+ * The same outputs as mused_knn_fused for the window whose row 0 is stream row lo_abs, computed from what the previous call
+ * on the SAME workspace (the window n_new rows earlier) left behind: rows that stay keep their candidate lists minus the
+ * columns that left; only the tiles involving one of the n_new entering rows (the LAST n_new rows of X) are evaluated:
+ * 1 - (1 - n_new / n)^2 of the similarity work.  n_new = 0: from scratch (first window, or after a flag).  *flag_out
+ * (device int) != 0: outputs INVALID (bit 0 a list overflowed, bit 1 a kept list no longer proves its row's k smallest) --
+ * repeat with n_new = 0.  Bit-identical to mused_knn_fused on the same window. */
+int mused_knn_fused_hop(const void* X, int dtype, long n, int d, long ld, int k, int metric, void* ws, long ws_bytes,
+                        int cap, long lo_abs, int n_new, int* out_idx, unsigned long long* out_mask, int mask_words,
+                        int* flag_out, void* stream);
+
 /* ---- a8: randomized truncated SVD (perform_svd_reduction, matrix_operations.py:143-147) ------ */
 
 int mused_rsvd_create(int n_max, int r_max, long nnz_cap, int sweeps, void** handle);

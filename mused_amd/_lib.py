@@ -34,6 +34,7 @@ _PROTOS = {
     "mused_knn_topk": (_i, [_vp, _i, _l, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "mused_knn_fused_ws_bytes": (_l, [_l, _i]),
     "mused_knn_fused": (_i, [_vp, _i, _l, _i, _l, _i, _i, _vp, _l, _i, _vp, _vp, _i, _vp, _vp]),
+    "mused_knn_fused_hop": (_i, [_vp, _i, _l, _i, _l, _i, _i, _vp, _l, _i, _l, _i, _vp, _vp, _i, _vp, _vp]),
     "mused_record_scores": (_i, [_vp, _i, _i, _vp, _vp]),
     "mused_group_mask": (_i, [_vp, _i, _vp, _i, _vp]),
     "mused_record_knn": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),

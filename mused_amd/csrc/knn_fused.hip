@@ -44,9 +44,18 @@ struct CandArgs {
   double* cscore;  // [n][cap]
   int* ccol;       // [n][cap]
   int cap;
-  int* overflow;   // device flag
+  int* overflow;   // device flag (bit 0: a list overflowed; bit 1, hop mode: a row's kept list no longer proves its top k)
   const double* nrm;  // squared norms (l2) / inverse norms (cosine), as in knn.hip
+  // Hopping windows (mused_knn_fused_hop): the per-row state lives in RING SLOTS keyed by stream position
+  // (slot of window row r = (r + slot_base) mod n), list entries carry ABSOLUTE column ids (window column + col_base), and
+  // pairs of rows that were both in the previous window (r, c < n_ret) are not recomputed.  Tumbling windows: 0, 0, 0.
+  int slot_base, col_base, n_ret, n;
 };
+
+__device__ __forceinline__ int cand_slot(const CandArgs& c, int row) {
+  const int s = row + c.slot_base;
+  return s >= c.n ? s - c.n : s;
+}
 
 template <int METRIC>
 __device__ __forceinline__ double score_of(const double* __restrict__ nrm, int row, int col, double v) {
@@ -57,11 +66,12 @@ __device__ __forceinline__ double score_of(const double* __restrict__ nrm, int r
   return 0.0 - (v * nrm[row] * nrm[col]);  // EpiNegCos::value (never -0.0)
 }
 
-__device__ __forceinline__ void cand_push(const CandArgs& c, int row, int col, double v) {
-  const int pos = atomicAdd(&c.count[row], 1);
+// slot: ring slot of the row; col: window column (stored as an absolute id)
+__device__ __forceinline__ void cand_push(const CandArgs& c, int slot, int col, double v) {
+  const int pos = atomicAdd(&c.count[slot], 1);
   if (pos < c.cap) {
-    c.cscore[(long)row * c.cap + pos] = v;
-    c.ccol[(long)row * c.cap + pos] = col;
+    c.cscore[(long)slot * c.cap + pos] = v;
+    c.ccol[(long)slot * c.cap + pos] = col + c.col_base;
   } else {
     atomicOr(c.overflow, 1);
   }
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void knn_band_kernel(GemmArgs g, C
   if (2 * delta == tiles && I >= tiles / 2) return;  // even tile count: the antipodal pairs once
   int J = I + delta;
   if (J >= tiles) J -= tiles;
+  if ((I + 1) * GEMM_BM <= c.n_ret && (J + 1) * GEMM_BN <= c.n_ret) return;  // hop mode: both row tiles were in the last window
   const int m0 = I * GEMM_BM, n0 = J * GEMM_BN;
   const T* X = reinterpret_cast<const T*>(g.A);
   v4f64 acc[4][4];
@@ -108,16 +119,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void knn_band_kernel(GemmArgs g, C
           const int cl = wc * 64 + j * 16 + li, col = n0 + cl;
           const double av = acc[i][j][r];
           if (row < n) {  // row side: columns of tile J at signed distance +delta
-            const long p = (long)row * c.cap + (a + delta) * 128 + cl;
+            const long p = (long)cand_slot(c, row) * c.cap + (a + delta) * 128 + cl;
             const bool ok = col < n;
             c.cscore[p] = ok ? score_of<METRIC>(c.nrm, row, col, av) : inf;
-            c.ccol[p] = ok ? col : 0x7fffffff;
+            c.ccol[p] = ok ? col + c.col_base : 0x7fffffff;
           }
           if (both && col < n) {  // mirrored: row `col` of tile J sees column `row` of tile I at signed distance -delta
-            const long p = (long)col * c.cap + (a - delta) * 128 + rl;
+            const long p = (long)cand_slot(c, col) * c.cap + (a - delta) * 128 + rl;
             const bool ok = row < n;
             c.cscore[p] = ok ? score_of<METRIC>(c.nrm, col, row, av) : inf;
-            c.ccol[p] = ok ? row : 0x7fffffff;
+            c.ccol[p] = ok ? row + c.col_base : 0x7fffffff;
           }
         }
       }
@@ -125,14 +136,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void knn_band_kernel(GemmArgs g, C
     return;
   }
   // scores are never -0.0 (l2: clamped to +0.0, cosine: 0.0 - x) nor NaN: comparing doubles orders them like their keys
+  // (thresholds compare ABSOLUTE column ids: taucol is one)
   double tcol[4];
-  int tccol[4];
+  int tccol[4], scol[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = n0 + wc * 64 + j * 16 + li;
     const bool ok = both && col < n;
-    tcol[j] = ok ? c.tau[col] : __longlong_as_double(0xfff0000000000000ll);  // -inf admits nothing
-    tccol[j] = ok ? c.taucol[col] : -1;
+    scol[j] = ok ? cand_slot(c, col) : 0;
+    tcol[j] = ok ? c.tau[scol[j]] : __longlong_as_double(0xfff0000000000000ll);  // -inf admits nothing
+    tccol[j] = ok ? c.taucol[scol[j]] : -1;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -140,18 +153,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void knn_band_kernel(GemmArgs g, C
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + wr * 64 + i * 16 + kq + 4 * r;
       if (row >= n) continue;
-      const double trow = c.tau[row];
-      const int crow = c.taucol[row];
+      const int srow = cand_slot(c, row);
+      const double trow = c.tau[srow];
+      const int crow = c.taucol[srow];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = n0 + wc * 64 + j * 16 + li;
         if (col >= n) continue;
+        if (row < c.n_ret && col < c.n_ret) continue;  // hop mode: this pair is in both rows' kept lists (or was never admitted)
         const double a = acc[i][j][r];
         const double v = score_of<METRIC>(c.nrm, row, col, a);
-        if (v < trow || (v == trow && col < crow)) cand_push(c, row, col, v);
+        if (v < trow || (v == trow && col + c.col_base < crow)) cand_push(c, srow, col, v);
         if (both) {
           const double v2 = score_of<METRIC>(c.nrm, col, row, a);  // evaluated in ITS orientation, as the classic path does
-          if (v2 < tcol[j] || (v2 == tcol[j] && row < tccol[j])) cand_push(c, col, row, v2);
+          if (v2 < tcol[j] || (v2 == tcol[j] && row + c.col_base < tccol[j])) cand_push(c, scol[j], row, v2);
         }
       }
     }
@@ -164,14 +179,22 @@ __device__ __forceinline__ double key_to_f64(unsigned long long k) {
   return __longlong_as_double((long long)u);
 }
 
+// row_lo: a non-final pass touches rows >= row_lo only (hop mode: the rows that entered with this window; the others keep
+// their list and threshold as they are).  check != 0 (final pass, hop mode): a row whose kept list no longer proves its
+// k smallest -- fewer than k candidates, the k-th above the row's threshold, or a list close to its capacity -- raises
+// bit 1 of the overflow word (the caller then recomputes the window from scratch).
 template <int PL>  // candidates per lane: cap <= 64 * PL
 __global__ __launch_bounds__(256) void cand_select_kernel(CandArgs c, int n, int k, int final, int* __restrict__ out_idx,
-                                                         unsigned long long* __restrict__ out_mask, int mask_words) {
+                                                         unsigned long long* __restrict__ out_mask, int mask_words,
+                                                         int row_lo, int check) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sel_lds[];  // final: [4 waves][mask_words] bit rows + [4][k] ints
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= n) return;
+  const int wrow = blockIdx.x * 4 + wave;  // window row
+  if (wrow >= n) return;
+  if (!final && wrow < row_lo) return;
+  const int row = cand_slot(c, wrow);      // its ring slot: where the list, the counter and the threshold live
   int cnt = c.count[row];
+  if (check && lane == 0 && (cnt < (k < n ? k : n) || cnt > c.cap - 64)) atomicOr(c.overflow, 2);
   cnt = cnt < c.cap ? cnt : c.cap;
   if (!final && cnt <= k) return;  // fewer candidates than wanted: nothing to tighten yet (tau stays)
   const int kk = k < cnt ? k : cnt;
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void cand_select_kernel(CandArgs c, int n, int
     base += __popcll(bal);
   }
   wave_lds_fence();
-  if (!final) {
+  if (!final || check) {
     // the k-th candidate in (score, column) order: the selected one with key == thr of LARGEST column
     int cmax = -1;
 #pragma unroll
@@ -309,26 +332,33 @@ __global__ __launch_bounds__(256) void cand_select_kernel(CandArgs c, int n, int
       const int x = __shfl_xor(cmax, o);
       cmax = x > cmax ? x : cmax;
     }
-    if (lane == 0) {
-      c.count[row] = kk;
-      c.tau[row] = key_to_f64(thr);
-      c.taucol[row] = cmax;
+    if (!final) {
+      if (lane == 0) {
+        c.count[row] = kk;
+        c.tau[row] = key_to_f64(thr);
+        c.taucol[row] = cmax;
+      }
+      return;
     }
-    return;
+    // hop mode: the kept list is complete below (tau, taucol) only -- the k-th must lie inside that region
+    if (lane == 0) {
+      const double tk = key_to_f64(thr), tr = c.tau[row];
+      if (!(tk < tr || (tk == tr && cmax <= c.taucol[row]))) atomicOr(c.overflow, 2);
+    }
   }
   // final pass: neighbour list in ascending column order, adjacency bitmask row with the own column cleared
   // (LDS writes and reads of one wave complete in order: no barrier)
   for (int j = lane; j < kk; j += 64) {
-    const int cj = fcols[j];
+    const int cj = fcols[j] - c.col_base;  // window column
     int rank = 0;
-    for (int m = 0; m < kk; ++m) rank += fcols[m] < cj;
-    if (out_idx) out_idx[(long)row * k + rank] = cj;
-    if (cj != row) atomicOr(&bits[cj >> 5], 1u << (cj & 31));
+    for (int m = 0; m < kk; ++m) rank += fcols[m] < fcols[j];
+    if (out_idx) out_idx[(long)wrow * k + rank] = cj;
+    if (cj != wrow && cj >= 0 && cj < n) atomicOr(&bits[cj >> 5], 1u << (cj & 31));
   }
   wave_lds_fence();
   if (out_mask) {
     const unsigned long long* b64 = reinterpret_cast<const unsigned long long*>(bits);
-    for (int w = lane; w < mask_words; w += 64) out_mask[(long)row * mask_words + w] = b64[w];
+    for (int w = lane; w < mask_words; w += 64) out_mask[(long)wrow * mask_words + w] = b64[w];
   }
 }
 
@@ -341,6 +371,44 @@ __global__ void cand_init_kernel(double* __restrict__ tau, int* __restrict__ tau
     count[i] = count0;  // DIRECT first phase: its fixed number of slots per row
   }
   if (i == 0) *overflow = 0;
+}
+
+// Hop mode, start of a window: rows that were in the previous window drop the candidates whose column has left the window
+// (absolute id < col_base) -- what stays is still every window column below the row's threshold --; the slots of the rows
+// that enter are reset.  One wave per window row.
+__global__ __launch_bounds__(256) void cand_expire_kernel(CandArgs c, int n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wrow = blockIdx.x * 4 + wave;
+  if (wrow >= n) return;
+  const int row = cand_slot(c, wrow);
+  if (wrow >= c.n_ret) {
+    if (lane == 0) {
+      c.count[row] = 0;
+      c.tau[row] = __longlong_as_double(0x7ff0000000000000ll);
+      c.taucol[row] = 0x7fffffff;
+    }
+    return;
+  }
+  int cnt = c.count[row];
+  cnt = cnt < c.cap ? cnt : c.cap;
+  double* sc = c.cscore + (long)row * c.cap;
+  int* cc = c.ccol + (long)row * c.cap;
+  int base = 0;
+  for (int p0 = 0; p0 < cnt; p0 += 64) {  // in place: a chunk is read before anything of it or behind it is written
+    const int p = p0 + lane;
+    const bool ok = p < cnt;
+    const double v = ok ? sc[p] : 0.0;
+    const int col = ok ? cc[p] : 0;
+    const bool keep = ok && col >= c.col_base;
+    const unsigned long long bal = __ballot(keep);
+    if (keep) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      sc[pos] = v;
+      cc[pos] = col;
+    }
+    base += __popcll(bal);
+  }
+  if (lane == 0) c.count[row] = base;
 }
 
 struct KnnFusedWs {
@@ -391,26 +459,32 @@ static int band_launch(const GemmArgs& g, const CandArgs& c, bool vec, int tiles
   return MUSED_OK;
 }
 
+// lo_abs: stream position of window row 0 (0 for tumbling use); n_new: 0 = compute the window from scratch, else the number
+// of rows at the END of the window that were not in the previous one (hop mode: the rest reuse their kept lists)
 template <typename T>
 static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, const KnnFusedWs& ws, int cap, int* out_idx,
-                       unsigned long long* out_mask, int mask_words, hipStream_t st) {
+                       unsigned long long* out_mask, int mask_words, hipStream_t st, long lo_abs = 0, int n_new = 0,
+                       bool ring = false) {
   const int tiles = cdiv(n, GEMM_BM);
   const int hmax = tiles / 2;
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = X; g.B = X; g.lda = ld; g.ldb = ld; g.M = (int)n; g.N = (int)n; g.K = d;
-  CandArgs c{ws.tau, ws.taucol, ws.count, ws.cscore, ws.ccol, cap, ws.overflow, ws.norms};
+  const bool hop = ring && n_new > 0 && n_new < n;
+  CandArgs c{ws.tau, ws.taucol, ws.count, ws.cscore, ws.ccol, cap, ws.overflow, ws.norms,
+             ring ? (int)(lo_abs % n) : 0, ring ? (int)(lo_abs & 0x3fffffff) : 0, hop ? (int)(n - n_new) : 0, (int)n};
   const bool vec = vec_ok<T>(X, ld, 0);
   const int pl = cdiv(cap, 64);
   const size_t sel_lds = 4 * ((size_t)mask_words * 8 + (size_t)k * 4) + 16;
+  const int row_lo = hop ? (int)(n - n_new) : 0, check = hop ? 1 : 0;
   auto select = [&](int final) {
     int* oi = final ? out_idx : nullptr;
     unsigned long long* om = final ? out_mask : nullptr;
     const size_t lds = final ? sel_lds : 0;
     const dim3 grid(cdiv(n, 4)), blk(256);
-    if (pl <= 4) hipLaunchKernelGGL(cand_select_kernel<4>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words);
-    else if (pl <= 8) hipLaunchKernelGGL(cand_select_kernel<8>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words);
-    else hipLaunchKernelGGL(cand_select_kernel<16>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words);
+    if (pl <= 4) hipLaunchKernelGGL(cand_select_kernel<4>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words, row_lo, check);
+    else if (pl <= 8) hipLaunchKernelGGL(cand_select_kernel<8>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words, row_lo, check);
+    else hipLaunchKernelGGL(cand_select_kernel<16>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words, row_lo, check);
   };
   auto band = [&](int d_lo, int nd, bool direct) -> int {
     if (metric == 0) return direct ? band_launch<T, 0, true>(g, c, vec, tiles, d_lo, nd, st) : band_launch<T, 0, false>(g, c, vec, tiles, d_lo, nd, st);
@@ -422,10 +496,16 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   // as twice that estimate fits the lists, otherwise the next phase triples the columns seen.
   int a = 2;
   while (a > 0 && ((2 * a + 1) * 128 > cap || k > (2 * a) * 128)) --a;
-  const bool direct = tiles >= 2 * a + 2 && (2 * a + 1) * 128 <= cap && a <= hmax;
+  // (hop mode: the rows that stay keep their lists; the rows that enter start from empty lists -- no fixed-slot first phase)
+  const bool direct = !hop && tiles >= 2 * a + 2 && (2 * a + 1) * 128 <= cap && a <= hmax;
   int d_hi = direct ? a : (hmax < 1 ? hmax : 1);
-  hipLaunchKernelGGL(cand_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws.tau, ws.taucol, ws.count, ws.overflow,
-                     (int)n, direct ? (2 * a + 1) * 128 : 0);
+  if (hop) {
+    MUSED_CHECK_HIP(hipMemsetAsync(ws.overflow, 0, 4, st));
+    hipLaunchKernelGGL(cand_expire_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, c, (int)n);
+  } else {
+    hipLaunchKernelGGL(cand_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws.tau, ws.taucol, ws.count, ws.overflow,
+                       (int)n, direct ? (2 * a + 1) * 128 : 0);
+  }
   int rc;
   int d_lo = 0;
   while (true) {
@@ -483,6 +563,44 @@ int mused_knn_fused(const void* X, int dtype, long n, int d, long ld, int k, int
   }
   if (rc) return rc;
   if (overflow_out) MUSED_CHECK_HIP(hipMemcpyAsync(overflow_out, w.overflow, 4, hipMemcpyDeviceToDevice, st));
+  return MUSED_OK;
+}
+
+// Hopping windows (step_window_ratio > 1, main.py:32): the same result as mused_knn_fused for the window
+// whose row 0 is stream row `lo_abs`, reusing what the previous call on the SAME workspace (for the window n_new rows
+// earlier) left behind: a row that stays in the window keeps its candidate list -- every window column below its threshold --
+// minus the columns that left; only the tiles that involve one of the n_new rows at the end of the window are computed
+// (1 - (1 - n_new / n)^2 of them), which serve the entering rows (all their columns) and the staying rows (their scores against
+// the entering columns).  n_new = 0 (or >= n): compute from scratch and leave the state for the next call.
+// *flag_out (device int): bit 0 a list overflowed, bit 1 a kept list no longer proves its row's k smallest -- in either case
+// the outputs are INVALID and the call has to be repeated with n_new = 0.  The workspace must not be used for anything else
+// in between; X must hold the n window rows in stream order (row i = stream row lo_abs + i).
+int mused_knn_fused_hop(const void* X, int dtype, long n, int d, long ld, int k, int metric, void* ws, long ws_bytes, int cap,
+                        long lo_abs, int n_new, int* out_idx, unsigned long long* out_mask, int mask_words, int* flag_out,
+                        void* stream) {
+  MUSED_REQUIRE(X && ws && n > 0 && d > 0 && ld >= d && k >= 1 && k <= n, "mused_knn_fused_hop: bad arguments (k=%d n=%ld)", k, n);
+  MUSED_REQUIRE(metric == 0 || metric == 1, "mused_knn_fused_hop: metric must be 0 (l2) or 1 (cosine)");
+  MUSED_REQUIRE(cap >= k && cap <= 1024, "mused_knn_fused_hop: need k <= cap <= 1024");
+  MUSED_REQUIRE(lo_abs >= 0 && n_new >= 0, "mused_knn_fused_hop: negative stream position / row count");
+  MUSED_REQUIRE(lo_abs + n < (1l << 30), "mused_knn_fused_hop: stream positions beyond 2^30 (column ids are 32-bit)");
+  MUSED_REQUIRE(n < (1l << 30) && (!out_mask || mask_words >= (n + 63) / 64), "mused_knn_fused_hop: mask_words too small");
+  MUSED_REQUIRE(ws_bytes >= (long)knn_fused_layout(n, cap, nullptr, nullptr), "mused_knn_fused_hop: workspace too small");
+  MUSED_REQUIRE((size_t)4 * ((size_t)mask_words * 8 + (size_t)k * 4) + 16 <= 64 * 1024, "mused_knn_fused_hop: window too long for the LDS bit rows");
+  hipStream_t st = (hipStream_t)stream;
+  KnnFusedWs w;
+  knn_fused_layout(n, cap, (char*)ws, &w);
+  int rc = mused_row_sq_norms(X, dtype, n, d, ld, w.norms, stream);
+  if (rc) return rc;
+  if (metric == 1 && (rc = inv_norms_launch(w.norms, n, st))) return rc;
+  const int nn = (n_new >= n) ? 0 : n_new;
+  if (dtype == MUSED_F32) rc = knn_fused_t<float>((const float*)X, n, d, ld, k, metric, w, cap, out_idx, out_mask, mask_words, st, lo_abs, nn, true);
+  else if (dtype == MUSED_F64) rc = knn_fused_t<double>((const double*)X, n, d, ld, k, metric, w, cap, out_idx, out_mask, mask_words, st, lo_abs, nn, true);
+  else {
+    set_error("mused_knn_fused_hop: unsupported dtype %d", dtype);
+    return MUSED_ERR_UNSUPPORTED;
+  }
+  if (rc) return rc;
+  if (flag_out) MUSED_CHECK_HIP(hipMemcpyAsync(flag_out, w.overflow, 4, hipMemcpyDeviceToDevice, st));
   return MUSED_OK;
 }
 

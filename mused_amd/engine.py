@@ -150,6 +150,8 @@ class WindowEngine:
         self.defer = False
         self._defer_slot = 0
         self.knn_fallbacks = 0  # windows redone on the classic path because a candidate list overflowed
+        self._hop = {}          # hopping windows: key -> workspace + stream position of the window it holds (knn_adjacency_hop)
+        self.hop_windows = self.hop_reused = self.hop_recomputes = 0
         self._rsvd = None
         self._rsvd_fb = None       # fallback handle (mode 2), created on first use
         self._rsvd_fb_key = None
@@ -253,6 +255,53 @@ class WindowEngine:
                  stream_ptr())
         adj = Adjacency(mask, n)
         return (adj, idx) if want_idx else adj
+
+    # ---- f3: hopping windows with reuse across consecutive windows -----------------------
+    def knn_adjacency_hop(self, rows, k: int, metric: str, key, lo: int):
+        """`knn_adjacency` for the window whose first row is stream row `lo`, reusing the candidate lists the previous call
+        with the same `key` (one per modality of a stream) left behind when that window overlaps this one
+        (step_window_ratio > 1, main.py:32): only the tiles that involve an entering row are computed.  Falls back to a
+        computation from scratch when there is nothing to reuse, and repeats from scratch when the device reports that a
+        kept list no longer proves a row's k smallest (one small blocking read per window in this mode).  Bit-identical to
+        `knn_adjacency` on the same rows."""
+        X = to_device_rows(rows, self.device)
+        n, d = X.shape
+        if metric == "l2":
+            kk, m = max(1, int(k)), METRIC_L2
+            if kk > n:
+                raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {kk}, n_samples_fit = {n}, "
+                                 f"n_samples = {n}")
+        else:
+            kk, m = min(int(k) + 1, n), METRIC_COSINE
+        cap = max(704, ((4 * kk + 128 + 63) // 64) * 64)
+        if self.knn_mode == "classic" or cap > 1024 or kk > cap:
+            return self.knn_adjacency(X, k, metric)
+        st = self._hop.get(key)
+        if st is None or st["n"] != n or st["cap"] != cap or st["d"] != d or st["kk"] != kk:
+            nbytes = int(_lib.lib().mused_knn_fused_ws_bytes(n, cap))
+            st = self._hop[key] = dict(ws=torch.empty(nbytes, dtype=torch.uint8, device=self.device), n=n, cap=cap, d=d, kk=kk,
+                                       lo=None, flag=torch.zeros(1, dtype=torch.int32, device=self.device))
+        n_new = 0
+        if st["lo"] is not None and 0 < lo - st["lo"] < n:
+            n_new = lo - st["lo"]
+        w = words_for(n)
+        mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+        for attempt in range(2):
+            call("mused_knn_fused_hop", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(st["ws"]), st["ws"].numel(), cap,
+                 int(lo), int(n_new), None, ptr(mask), w, ptr(st["flag"]), stream_ptr())
+            flag = int(st["flag"].item())
+            if flag == 0:
+                break
+            if n_new == 0:  # from scratch and still flagged: a list overflowed (thousands of equal scores) -> classic path
+                st["lo"] = None
+                self.knn_fallbacks += 1
+                return self.knn_adjacency(X, k, metric)
+            self.hop_recomputes += 1
+            n_new = 0
+        st["lo"] = int(lo)
+        self.hop_windows += 1
+        self.hop_reused += 1 if (attempt == 0 and n_new > 0) else 0
+        return Adjacency(mask, n)
 
     # ---- a1, metadata modality types (SURVEY 8 f4; csrc/meta.hip) ------------------------
     def _select(self, n: int, kk: int) -> Adjacency:

@@ -73,6 +73,8 @@ class StreamPipeline:
         self.redone_windows = 0
         self._nnz_hint = 0         # edges of the densest window seen so far ("username": no a-priori bound)
         self._closed = False
+        # reuse across hopping windows: one engine, every window in order (MUSED_HOP_REUSE=0 turns it off)
+        self._hop_reuse = (int(step_window_ratio) > 1 and self._nslots == 1 and os.environ.get("MUSED_HOP_REUSE", "1") != "0")
         self._slots = None        # [(engine, stream)], built at the first window
         self._nwin = 0
         self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)
@@ -129,20 +131,23 @@ class StreamPipeline:
         self._device = torch.cuda.current_device()  # worker threads must select it themselves
 
     # ---- device side of one window --------------------------------------------------------------
-    def window_device(self, mods, eng=None, defer=False):
+    def window_device(self, mods, eng=None, defer=False, lo=None):
         """mods: list of (W, d_m) float32/float64 tensors on the device.  Returns (reduced (W, m) CUDA
         tensor, sigma CUDA tensor, flags): flags = None (sketch approaches), the eigenstep's int32[4] flag word, or with
         `defer` the int32[12] word of `WindowEngine.window_flags` (nothing read on this thread)."""
         eng = eng or self.eng
         eng.begin_window(defer)
         try:
-            return self._window_device(mods, eng, defer)
+            return self._window_device(mods, eng, defer, lo)
         finally:
             eng.defer = False  # direct callers of the engine get finished results again
 
-    def _window_device(self, mods, eng, defer):
+    def _window_device(self, mods, eng, defer, lo=None):
         types = self.types or [""] * len(mods)
-        adjs = [self._adjacency(m, t, eng) for m, t in zip(mods, types)]
+        # hopping windows (step_window_ratio > 1): consecutive windows share rows -> the dense modalities reuse their
+        # candidate lists across windows (SURVEY 8 f3; engine.knn_adjacency_hop).  `lo` = stream row of the window's row 0.
+        reuse = lo is not None and self._hop_reuse and eng is self.eng
+        adjs = [self._adjacency(m, t, eng, hop=((i, lo) if reuse else None)) for i, (m, t) in enumerate(zip(mods, types))]
         fused = eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
         if len(adjs) == 1:
             fused.fused = False
@@ -185,7 +190,7 @@ class StreamPipeline:
             flags = eng.window_flags(flags)
         return emb, sigma, flags
 
-    def _adjacency(self, m, t, eng=None):
+    def _adjacency(self, m, t, eng=None, hop=None):
         """One modality of one window -> device adjacency, with the reference's row filtering."""
         eng = eng or self.eng
         if t == "text" or t in mo._METADATA_TYPES or not isinstance(m, torch.Tensor):
@@ -213,6 +218,8 @@ class StreamPipeline:
                 ok = bool(torch.isfinite(m).all().item())
             if not ok:
                 return mo.adjacency_on_device(m, t, self.k, engine=eng)
+        if hop is not None:
+            return eng.knn_adjacency_hop(m, self.k, metric, key=hop[0], lo=hop[1])
         return eng.knn_adjacency(m, self.k, metric)
 
     # ---- host consumers -------------------------------------------------------------------------
@@ -300,7 +307,7 @@ class StreamPipeline:
             return (torch.empty(reduced.shape, dtype=reduced.dtype, pin_memory=True),
                     torch.empty(sigma.shape, dtype=sigma.dtype, pin_memory=True))
 
-    def _device_side(self, mods, n_clusters, trigger, t_start, eng, st, wait_ev):
+    def _device_side(self, mods, n_clusters, trigger, t_start, eng, st, wait_ev, lo=None):
         """Enqueue one window on (eng, st); returns the job the label workers consume."""
         torch.cuda.set_device(self._device)
         if wait_ev is not None:
@@ -310,7 +317,7 @@ class StreamPipeline:
                 for m in mods:
                     if isinstance(m, torch.Tensor):
                         m.record_stream(st)
-            reduced, sigma, flags = self.window_device(mods, eng, defer=self._defer)
+            reduced, sigma, flags = self.window_device(mods, eng, defer=self._defer, lo=lo)
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)  # window latency includes the sketch
             red_pin, sig_pin = self._get_pins(reduced, sigma)
@@ -333,7 +340,9 @@ class StreamPipeline:
     def _chain_after(self, fut_cluster, fut_job):
         return self._chain(fut_cluster, fut_job.result())
 
-    def process_window(self, mods, true_labels_window, trigger=None):
+    def process_window(self, mods, true_labels_window, trigger=None, lo=None):
+        """One full window.  `lo`: stream row of its first row -- given for hopping windows it lets the dense modalities
+        reuse the previous window's similarity work (only with one engine and windows handed in in order)."""
         t_start = time.perf_counter()
         n_clusters = len(np.unique(true_labels_window))  # main.py:41
         caller = torch.cuda.current_stream()
@@ -368,7 +377,7 @@ class StreamPipeline:
         if self._nslots == 1 or self._pool is None:
             if self._nslots > 1:
                 st.wait_stream(caller)
-            job = self._device_side(mods, n_clusters, trigger, t_start, eng, st, None)
+            job = self._device_side(mods, n_clusters, trigger, t_start, eng, st, None, lo)
             if self._pool is None:
                 self._chain(self._cluster(job), job)
             else:
@@ -414,7 +423,8 @@ class StreamPipeline:
         for i in range(n):
             if i + 1 >= self.W and (i + 1) * self.ratio % self.W == 0:  # main.py:32
                 lo = i + 1 - self.W
-                self.process_window([m[lo : i + 1] for m in dev], true_labels[lo : i + 1], trigger=i)
+                self.process_window([m[lo : i + 1] for m in dev], true_labels[lo : i + 1], trigger=i,
+                                    lo=lo if self.ratio > 1 else None)
         self.flush()
         return np.array(self.out)
 
