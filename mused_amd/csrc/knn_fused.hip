@@ -477,14 +477,25 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   const int pl = cdiv(cap, 64);
   const size_t sel_lds = 4 * ((size_t)mask_words * 8 + (size_t)k * 4) + 16;
   const int row_lo = hop ? (int)(n - n_new) : 0, check = hop ? 1 : 0;
+  // Ring mode keeps a MARGIN for the next window: thresholds (and the compaction between the phases) follow the
+  // (3 k)-th smallest score instead of the k-th, so a kept list holds ~3 k (W / columns seen before the last phase) columns
+  // below its threshold, of which a hop removes the share that left the window: the k smallest of the next window are
+  // then provable from the list with room to spare (the final pass still outputs the k smallest).
+  int kthr = k;
+  if (ring) {
+    kthr = 3 * k;
+    if (kthr > cap / 4) kthr = cap / 4;
+    if (kthr < k) kthr = k;
+  }
   auto select = [&](int final) {
     int* oi = final ? out_idx : nullptr;
     unsigned long long* om = final ? out_mask : nullptr;
     const size_t lds = final ? sel_lds : 0;
+    const int ks = final ? k : kthr;
     const dim3 grid(cdiv(n, 4)), blk(256);
-    if (pl <= 4) hipLaunchKernelGGL(cand_select_kernel<4>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words, row_lo, check);
-    else if (pl <= 8) hipLaunchKernelGGL(cand_select_kernel<8>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words, row_lo, check);
-    else hipLaunchKernelGGL(cand_select_kernel<16>, grid, blk, lds, st, c, (int)n, k, final, oi, om, mask_words, row_lo, check);
+    if (pl <= 4) hipLaunchKernelGGL(cand_select_kernel<4>, grid, blk, lds, st, c, (int)n, ks, final, oi, om, mask_words, row_lo, check);
+    else if (pl <= 8) hipLaunchKernelGGL(cand_select_kernel<8>, grid, blk, lds, st, c, (int)n, ks, final, oi, om, mask_words, row_lo, check);
+    else hipLaunchKernelGGL(cand_select_kernel<16>, grid, blk, lds, st, c, (int)n, ks, final, oi, om, mask_words, row_lo, check);
   };
   auto band = [&](int d_lo, int nd, bool direct) -> int {
     if (metric == 0) return direct ? band_launch<T, 0, true>(g, c, vec, tiles, d_lo, nd, st) : band_launch<T, 0, false>(g, c, vec, tiles, d_lo, nd, st);
@@ -495,7 +506,7 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   // row that has seen m columns admits about k / m of what it is shown: the remaining distances go in ONE launch as soon
   // as twice that estimate fits the lists, otherwise the next phase triples the columns seen.
   int a = 2;
-  while (a > 0 && ((2 * a + 1) * 128 > cap || k > (2 * a) * 128)) --a;
+  while (a > 0 && ((2 * a + 1) * 128 > cap || kthr > (2 * a) * 128)) --a;
   // (hop mode: the rows that stay keep their lists; the rows that enter start from empty lists -- no fixed-slot first phase)
   const bool direct = !hop && tiles >= 2 * a + 2 && (2 * a + 1) * 128 <= cap && a <= hmax;
   int d_hi = direct ? a : (hmax < 1 ? hmax : 1);
@@ -516,8 +527,8 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
     if (last) break;
     d_lo = d_hi + 1;
     const long seen = (2l * d_hi + 1) * 128, left = (long)n - seen;
-    const long est = left > 0 ? ((long)k * left + seen - 1) / seen : 0;
-    d_hi = (k + 2 * est <= cap) ? hmax : 3 * d_hi + 2;
+    const long est = left > 0 ? ((long)kthr * left + seen - 1) / seen : 0;
+    d_hi = (kthr + 2 * est <= cap) ? hmax : 3 * d_hi + 2;
   }
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
