@@ -25,6 +25,8 @@
 // re-reading the score matrix, and a 61 MB workspace instead of 800 MB.  Lists are bounded by `cap` per row; if
 // any row overflows (pathological inputs: thousands of exactly equal scores) a device flag is raised and the caller
 // falls back to the classic path -- never a wrong result.
+#include <vector>
+
 #include "gemm_f64.h"
 #include "internal.h"
 
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void cand_select_kernel(CandArgs c, int n, int
   if (!final && wrow < row_lo) return;
   const int row = cand_slot(c, wrow);      // its ring slot: where the list, the counter and the threshold live
   int cnt = c.count[row];
-  if (check && lane == 0 && (cnt < (k < n ? k : n) || cnt > c.cap - 64)) atomicOr(c.overflow, 2);
+  if (final && check && lane == 0 && (cnt < (k < n ? k : n) || cnt > c.cap - 64)) atomicOr(c.overflow, 2);
   cnt = cnt < c.cap ? cnt : c.cap;
   if (!final && cnt <= k) return;  // fewer candidates than wanted: nothing to tighten yet (tau stays)
   const int kk = k < cnt ? k : cnt;
@@ -511,7 +513,9 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   const bool direct = !hop && tiles >= 2 * a + 2 && (2 * a + 1) * 128 <= cap && a <= hmax;
   int d_hi = direct ? a : (hmax < 1 ? hmax : 1);
   if (hop) {
-    MUSED_CHECK_HIP(hipMemsetAsync(ws.overflow, 0, 4, st));
+    // (the flag word is NOT cleared: once a list has overflowed or stopped proving its row's k smallest, every window built
+    // on this state reports it until a computation from scratch -- n_new = 0 -- resets state and flag; the caller may
+    // therefore read the flag late, behind several windows)
     hipLaunchKernelGGL(cand_expire_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, c, (int)n);
   } else {
     hipLaunchKernelGGL(cand_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws.tau, ws.taucol, ws.count, ws.overflow,
@@ -519,16 +523,36 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   }
   int rc;
   int d_lo = 0;
+  static const bool trace = getenv("MUSED_HOP_TRACE") != nullptr;
+  auto dump = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(st);
+    std::vector<int> cnt(n);
+    int fl = 0;
+    (void)hipMemcpy(cnt.data(), ws.count, 4 * (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&fl, ws.overflow, 4, hipMemcpyDeviceToHost);
+    int mx = 0, mxi = 0;
+    for (long i = 0; i < n; ++i) if (cnt[i] > mx) { mx = cnt[i]; mxi = (int)i; }
+    fprintf(stderr, "[knn trace] %s: flag %d, max count %d at slot %d (cap %d, hop %d, n_ret %d, kthr %d)\n", what, fl, mx, mxi, cap,
+            (int)hop, c.n_ret, kthr);
+  };
+  dump("start");
   while (true) {
     if (d_hi > hmax) d_hi = hmax;
     if ((rc = band(d_lo, d_hi - d_lo + 1, direct && d_lo == 0))) return rc;
+    if (trace) fprintf(stderr, "[knn trace] band delta %d..%d\n", d_lo, d_hi);
+    dump("after band");
     const bool last = d_hi >= hmax;
     select(last ? 1 : 0);
+    dump("after select");
     if (last) break;
     d_lo = d_hi + 1;
     const long seen = (2l * d_hi + 1) * 128, left = (long)n - seen;
     const long est = left > 0 ? ((long)kthr * left + seen - 1) / seen : 0;
-    d_hi = (kthr + 2 * est <= cap) ? hmax : 3 * d_hi + 2;
+    // (ring mode: the threshold follows the (3 k)-th score, a phase that triples the columns seen would admit ~2 x 3 k with
+    // a wide spread between rows on clustered data -- the columns seen double instead, and the last phase needs more room)
+    if (ring) d_hi = (kthr + 3 * est <= cap) ? hmax : 2 * d_hi + 1;
+    else d_hi = (kthr + 2 * est <= cap) ? hmax : 3 * d_hi + 2;
   }
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
@@ -584,7 +608,9 @@ int mused_knn_fused(const void* X, int dtype, long n, int d, long ld, int k, int
 // (1 - (1 - n_new / n)^2 of them), which serve the entering rows (all their columns) and the staying rows (their scores against
 // the entering columns).  n_new = 0 (or >= n): compute from scratch and leave the state for the next call.
 // *flag_out (device int): bit 0 a list overflowed, bit 1 a kept list no longer proves its row's k smallest -- in either case
-// the outputs are INVALID and the call has to be repeated with n_new = 0.  The workspace must not be used for anything else
+// the outputs are INVALID and the call has to be repeated with n_new = 0.  The flag is STICKY: every later call that reuses
+// this state reports it too, until a call with n_new = 0 -- so a caller may enqueue several windows before it reads the flag
+// of the first and then repeat the flagged ones.  The workspace must not be used for anything else
 // in between; X must hold the n window rows in stream order (row i = stream row lo_abs + i).
 int mused_knn_fused_hop(const void* X, int dtype, long n, int d, long ld, int k, int metric, void* ws, long ws_bytes, int cap,
                         long lo_abs, int n_new, int* out_idx, unsigned long long* out_mask, int mask_words, int* flag_out,

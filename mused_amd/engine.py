@@ -273,8 +273,8 @@ class WindowEngine:
                                  f"n_samples = {n}")
         else:
             kk, m = min(int(k) + 1, n), METRIC_COSINE
-        cap = max(704, ((4 * kk + 128 + 63) // 64) * 64)
-        if self.knn_mode == "classic" or cap > 1024 or kk > cap:
+        cap = 1024  # the kept lists follow the (3 k)-th score: room for 3 k + what a phase admits
+        if self.knn_mode == "classic" or 4 * kk + 128 > 1024:
             return self.knn_adjacency(X, k, metric)
         st = self._hop.get(key)
         if st is None or st["n"] != n or st["cap"] != cap or st["d"] != d or st["kk"] != kk:
@@ -282,10 +282,23 @@ class WindowEngine:
             st = self._hop[key] = dict(ws=torch.empty(nbytes, dtype=torch.uint8, device=self.device), n=n, cap=cap, d=d, kk=kk,
                                        lo=None, flag=torch.zeros(1, dtype=torch.int32, device=self.device))
         n_new = 0
-        if st["lo"] is not None and 0 < lo - st["lo"] < n:
+        if st["lo"] is not None and not st.get("reset") and 0 < lo - st["lo"] < n:
             n_new = lo - st["lo"]
+        st["reset"] = False
         w = words_for(n)
         mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
+        deferred = self.defer and self._defer_slot < 8
+        if deferred:
+            # the flag word (sticky on the device until the state is rebuilt) goes to the window's flag words; whoever reads
+            # them later repeats a flagged window elsewhere and sets st["reset"], which makes the next call start from scratch
+            fptr = C.c_void_p(self._ovf8.data_ptr() + 4 * self._defer_slot)
+            self._defer_slot += 1
+            call("mused_knn_fused_hop", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(st["ws"]), st["ws"].numel(), cap,
+                 int(lo), int(n_new), None, ptr(mask), w, fptr, stream_ptr())
+            st["lo"] = int(lo)
+            self.hop_windows += 1
+            self.hop_reused += 1 if n_new > 0 else 0
+            return Adjacency(mask, n)
         for attempt in range(2):
             call("mused_knn_fused_hop", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(st["ws"]), st["ws"].numel(), cap,
                  int(lo), int(n_new), None, ptr(mask), w, ptr(st["flag"]), stream_ptr())

@@ -241,6 +241,9 @@ class StreamPipeline:
             if redo:
                 # a candidate list overflowed / the final Cholesky-QR met a weak pivot / more edges than the optimistic
                 # bound: this window again, on the paths that have no such limits (rare; blocking on this worker only)
+                for i_, f_ in enumerate(flags_host[4:]):   # hopping-window reuse: rebuild that modality's state next window
+                    if f_ and i_ in self.eng._hop:
+                        self.eng._hop[i_]["reset"] = True
                 reduced_dev, sigma_dev, flags_host = self._redo_window(mods)
                 reduced_host, sigma_host = reduced_dev.cpu().numpy(), sigma_dev.cpu().numpy()
             WindowEngine.check_rsvd_flags(flags_host)  # raised on the label worker, surfaces in flush()

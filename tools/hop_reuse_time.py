@@ -16,8 +16,11 @@ for ratio in (1, 2, 4, 8):
     res = {}
     for mode in ("recompute", "reuse"):
         eng._hop.clear()
-        fn = (lambda lo: eng.knn_adjacency(X[lo:lo + W], k, "l2")) if mode == "recompute" else \
-             (lambda lo: eng.knn_adjacency_hop(X[lo:lo + W], k, "l2", key=0, lo=lo))
+        def fn(lo):
+            eng.begin_window(True)   # flags stay on the device, as in the pipeline (no host read per window)
+            if mode == "recompute":
+                return eng.knn_adjacency(X[lo:lo + W], k, "l2")
+            return eng.knn_adjacency_hop(X[lo:lo + W], k, "l2", key=0, lo=lo)
         fn(0)
         fn(hop)
         torch.cuda.synchronize()
@@ -28,6 +31,7 @@ for ratio in (1, 2, 4, 8):
         e1.record()
         torch.cuda.synchronize()
         res[mode + "_ms_per_window"] = e0.elapsed_time(e1) / nwin
+        res[mode + "_flags"] = int(eng._ovf8.sum().item())
     res["tile_fraction_1_minus_(1-1/ratio)^2"] = 1 - (1 - 1 / ratio) ** 2
     res["measured_fraction"] = res["reuse_ms_per_window"] / res["recompute_ms_per_window"]
     out["ratios"][str(ratio)] = res
