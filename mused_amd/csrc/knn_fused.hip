@@ -93,7 +93,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void knn_band_kernel(GemmArgs g, C
   const int per_group = 8 * n_delta;
   const int ig = e / per_group, rem = e - ig * per_group;
   const int delta = d_lo + rem / 8;
-  const int I = ig * 8 + (rem & 7);
+  // hop mode: at distance delta the tiles that involve an entering row are the contiguous range I >= t_new - delta (t_new =
+  // first tile that holds one): the grid enumerates only those (from the smallest start of the phase: a few idle
+  // workgroups per distance instead of 1 - (1 - 1 / ratio)^2 of the grid exiting at once, bunched on some XCDs)
+  const int t_new = c.n_ret / GEMM_BM;
+  const int ibase = t_new > delta ? t_new - delta : 0;
+  const int I = ibase + ig * 8 + (rem & 7);
   if (I >= tiles || 2 * delta > tiles) return;
   if (2 * delta == tiles && I >= tiles / 2) return;  // even tile count: the antipodal pairs once
   int J = I + delta;
@@ -454,7 +459,9 @@ static int band_launch(const GemmArgs& g, const CandArgs& c, bool vec, int tiles
     err[v] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
   });
   MUSED_CHECK_HIP(err[v]);
-  const dim3 grid(cdiv(tiles, 8) * 8 * nd), blk(GEMM_THREADS);
+  const int t_new = c.n_ret / GEMM_BM, d_hi_ = d_lo + nd - 1;
+  const int ibase_min = t_new > d_hi_ ? t_new - d_hi_ : 0;
+  const dim3 grid(cdiv(tiles - ibase_min, 8) * 8 * nd), blk(GEMM_THREADS);
   if (vec) hipLaunchKernelGGL((knn_band_kernel<T, true, METRIC, DIRECT>), grid, blk, GEMM_LDS_BYTES, st, g, c, tiles, d_lo, nd);
   else hipLaunchKernelGGL((knn_band_kernel<T, false, METRIC, DIRECT>), grid, blk, GEMM_LDS_BYTES, st, g, c, tiles, d_lo, nd);
   MUSED_LAUNCH_CHECK();
