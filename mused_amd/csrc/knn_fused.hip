@@ -116,26 +116,45 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void knn_band_kernel(GemmArgs g, C
   if constexpr (DIRECT) {
     const int a = n_delta - 1;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    const bool hopm = c.n_ret > 0;  // hop mode: fixed slots for the ENTERING rows only, threshold pushes for the staying ones
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = wr * 64 + i * 16 + kq + 4 * r, row = m0 + rl;
+        const bool row_new = row >= c.n_ret;
+        const int srow = row < n ? cand_slot(c, row) : 0;
+        double trow = 0.0;
+        int crow = 0;
+        if (hopm && !row_new && row < n) { trow = c.tau[srow]; crow = c.taucol[srow]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int cl = wc * 64 + j * 16 + li, col = n0 + cl;
           const double av = acc[i][j][r];
+          const bool col_new = col >= c.n_ret;
           if (row < n) {  // row side: columns of tile J at signed distance +delta
-            const long p = (long)cand_slot(c, row) * c.cap + (a + delta) * 128 + cl;
-            const bool ok = col < n;
-            c.cscore[p] = ok ? score_of<METRIC>(c.nrm, row, col, av) : inf;
-            c.ccol[p] = ok ? col + c.col_base : 0x7fffffff;
+            if (row_new) {
+              const long p = (long)srow * c.cap + (a + delta) * 128 + cl;
+              const bool ok = col < n;
+              c.cscore[p] = ok ? score_of<METRIC>(c.nrm, row, col, av) : inf;
+              c.ccol[p] = ok ? col + c.col_base : 0x7fffffff;
+            } else if (col_new && col < n) {
+              const double v = score_of<METRIC>(c.nrm, row, col, av);
+              if (v < trow || (v == trow && col + c.col_base < crow)) cand_push(c, srow, col, v);
+            }
           }
           if (both && col < n) {  // mirrored: row `col` of tile J sees column `row` of tile I at signed distance -delta
-            const long p = (long)cand_slot(c, col) * c.cap + (a - delta) * 128 + rl;
-            const bool ok = row < n;
-            c.cscore[p] = ok ? score_of<METRIC>(c.nrm, col, row, av) : inf;
-            c.ccol[p] = ok ? row + c.col_base : 0x7fffffff;
+            if (col_new) {
+              const long p = (long)cand_slot(c, col) * c.cap + (a - delta) * 128 + rl;
+              const bool ok = row < n;
+              c.cscore[p] = ok ? score_of<METRIC>(c.nrm, col, row, av) : inf;
+              c.ccol[p] = ok ? row + c.col_base : 0x7fffffff;
+            } else if (row_new && row < n) {
+              const int sc_ = cand_slot(c, col);
+              const double tc = c.tau[sc_];
+              const double v2 = score_of<METRIC>(c.nrm, col, row, av);
+              if (v2 < tc || (v2 == tc && row + c.col_base < c.taucol[sc_])) cand_push(c, sc_, row, v2);
+            }
           }
         }
       }
@@ -383,14 +402,14 @@ __global__ void cand_init_kernel(double* __restrict__ tau, int* __restrict__ tau
 // Hop mode, start of a window: rows that were in the previous window drop the candidates whose column has left the window
 // (absolute id < col_base) -- what stays is still every window column below the row's threshold --; the slots of the rows
 // that enter are reset.  One wave per window row.
-__global__ __launch_bounds__(256) void cand_expire_kernel(CandArgs c, int n) {
+__global__ __launch_bounds__(256) void cand_expire_kernel(CandArgs c, int n, int count0) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wrow = blockIdx.x * 4 + wave;
   if (wrow >= n) return;
   const int row = cand_slot(c, wrow);
   if (wrow >= c.n_ret) {
     if (lane == 0) {
-      c.count[row] = 0;
+      c.count[row] = count0;  // (the fixed slots of a DIRECT first phase, or nothing)
       c.tau[row] = __longlong_as_double(0x7ff0000000000000ll);
       c.taucol[row] = 0x7fffffff;
     }
@@ -487,12 +506,12 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   const size_t sel_lds = 4 * ((size_t)mask_words * 8 + (size_t)k * 4) + 16;
   const int row_lo = hop ? (int)(n - n_new) : 0, check = hop ? 1 : 0;
   // Ring mode keeps a MARGIN for the next window: thresholds (and the compaction between the phases) follow the
-  // (3 k)-th smallest score instead of the k-th, so a kept list holds ~3 k (W / columns seen before the last phase) columns
+  // (2 k)-th smallest score instead of the k-th, so a kept list holds ~2 k (W / columns seen before the last phase) columns
   // below its threshold, of which a hop removes the share that left the window: the k smallest of the next window are
   // then provable from the list with room to spare (the final pass still outputs the k smallest).
   int kthr = k;
   if (ring) {
-    kthr = 3 * k;
+    kthr = 2 * k;
     if (kthr > cap / 4) kthr = cap / 4;
     if (kthr < k) kthr = k;
   }
@@ -516,14 +535,14 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   // as twice that estimate fits the lists, otherwise the next phase triples the columns seen.
   int a = 2;
   while (a > 0 && ((2 * a + 1) * 128 > cap || kthr > (2 * a) * 128)) --a;
-  // (hop mode: the rows that stay keep their lists; the rows that enter start from empty lists -- no fixed-slot first phase)
-  const bool direct = !hop && tiles >= 2 * a + 2 && (2 * a + 1) * 128 <= cap && a <= hmax;
+  // (hop mode: the rows that stay keep their lists and receive pushes; the rows that enter get the fixed slots)
+  const bool direct = tiles >= 2 * a + 2 && (2 * a + 1) * 128 <= cap && a <= hmax;
   int d_hi = direct ? a : (hmax < 1 ? hmax : 1);
   if (hop) {
     // (the flag word is NOT cleared: once a list has overflowed or stopped proving its row's k smallest, every window built
     // on this state reports it until a computation from scratch -- n_new = 0 -- resets state and flag; the caller may
     // therefore read the flag late, behind several windows)
-    hipLaunchKernelGGL(cand_expire_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, c, (int)n);
+    hipLaunchKernelGGL(cand_expire_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, c, (int)n, direct ? (2 * a + 1) * 128 : 0);
   } else {
     hipLaunchKernelGGL(cand_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws.tau, ws.taucol, ws.count, ws.overflow,
                        (int)n, direct ? (2 * a + 1) * 128 : 0);
@@ -556,9 +575,9 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
     d_lo = d_hi + 1;
     const long seen = (2l * d_hi + 1) * 128, left = (long)n - seen;
     const long est = left > 0 ? ((long)kthr * left + seen - 1) / seen : 0;
-    // (ring mode: the threshold follows the (3 k)-th score, a phase that triples the columns seen would admit ~2 x 3 k with
-    // a wide spread between rows on clustered data -- the columns seen double instead, and the last phase needs more room)
-    if (ring) d_hi = (kthr + 3 * est <= cap) ? hmax : 2 * d_hi + 1;
+    // (ring mode: the threshold follows the (2 k)-th score and the lists have cap = 1024: a phase that triples the columns
+    // seen admits ~4 k on average with a wide spread between rows on clustered data; the last phase is given more room)
+    if (ring) d_hi = (kthr + 3 * est <= cap) ? hmax : 3 * d_hi + 2;
     else d_hi = (kthr + 2 * est <= cap) ? hmax : 3 * d_hi + 2;
   }
   MUSED_LAUNCH_CHECK();
