@@ -73,8 +73,13 @@ class StreamPipeline:
         self.redone_windows = 0
         self._nnz_hint = 0         # edges of the densest window seen so far ("username": no a-priori bound)
         self._closed = False
-        # reuse across hopping windows: one engine, every window in order (MUSED_HOP_REUSE=0 turns it off)
-        self._hop_reuse = (int(step_window_ratio) > 1 and self._nslots == 1 and os.environ.get("MUSED_HOP_REUSE", "1") != "0")
+        # reuse across hopping windows (one engine, every window in order).  Default: from ratio 4 on -- measured at config 2
+        # (W = 10^4, d = 1024, tools/hop_reuse_time.py): similarity + selection per window 2.70 ms from scratch, with reuse
+        # 2.90 ms at ratio 2 (the phases that establish the entering rows' thresholds run on too few tiles to fill the GPU),
+        # 2.19 ms at ratio 4, 1.96 ms at ratio 8.  MUSED_HOP_REUSE=1 / 0 forces it on (any ratio > 1) / off.
+        hr = os.environ.get("MUSED_HOP_REUSE")
+        self._hop_reuse = self._nslots == 1 and int(step_window_ratio) > 1 and (
+            hr == "1" or (hr != "0" and int(step_window_ratio) >= 4))
         self._slots = None        # [(engine, stream)], built at the first window
         self._nwin = 0
         self.swfd = None          # SWFDMC sketch over fused-adjacency rows (d = W)

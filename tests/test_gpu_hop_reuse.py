@@ -64,10 +64,12 @@ def test_reuse_survives_a_distribution_shift_and_gaps():
 
 
 @pytest.mark.parametrize("name,ratio", [("c1_stream_hop2_blob_s0", 2), ("c1_stream_hop4_gauss_s1", 4)])
-def test_pipeline_reuses_and_matches_reference_golden(name, ratio):
-    """The window loop with step_window_ratio 2 / 4 against the reference's own labels, with the reuse on (default) -- and
-    the engine reports that it reused."""
+def test_pipeline_reuses_and_matches_reference_golden(monkeypatch, name, ratio):
+    """The window loop with step_window_ratio 2 / 4 against the reference's own labels, with the reuse on (the default
+    from ratio 4; forced here for ratio 2 as well) -- and the engine reports that it reused."""
     from mused_amd.pipeline import StreamPipeline
+
+    monkeypatch.setenv("MUSED_HOP_REUSE", "1")
 
     g = load_golden(name)
     mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
