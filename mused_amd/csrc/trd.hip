@@ -365,17 +365,19 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
 }
 
 // ================= kernel B: the TM largest eigenvalues of T, NTB / 4 per workgroup (512 / NTB workgroups per matrix) =========
-// Sturm counts at NTB points first (log2(NTB + 1) bits for every eigenvalue), then passes of 5-section by the 4 lanes of a quad
-// (2.32 bits each).  NTB = 512: one workgroup per matrix, two waves per SIMD (full vector-ALU rate: large batches);
-// NTB = 128: four workgroups per matrix (small batches spread over the CUs they would leave idle).
+// Sturm counts at 512 equispaced points first (9 bits for every eigenvalue), then 19 passes of 5-section by the 4 lanes of a
+// quad (2.32 bits each).  NTB = 512: one workgroup per matrix, two waves per SIMD (full vector-ALU rate: large batches);
+// NTB = 128: four workgroups per matrix (small batches spread over the CUs they would leave idle; each evaluates all 512
+// points itself).  Both variants evaluate the same points in the same arithmetic: the eigenvalues do not depend on the
+// batch size (lock-step lanes == single sketches bit for bit).
 template <int NTB>
 __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
   constexpr int NCH = TNT / NTB, NWV = NTB / 64;
-  constexpr int PASSES = NTB == 512 ? 19 : (NTB == 256 ? 20 : 20);  // 5^19 x 513 > 2^53, 5^20 x 129 > 2^53
+  constexpr int PASSES = 19, NPT = 512;  // 5^19 x 513 > 2^53
   __shared__ __attribute__((aligned(16))) double2 dd2[TN];
   __shared__ double part[3 * NWV];
   __shared__ double scal[4];
-  __shared__ int cnts[NTB];
+  __shared__ int cnts[NPT];
   const int bm = blockIdx.x / NCH, cq = blockIdx.x % NCH;
   if (rep && rep[bm] != bm) return;
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -415,16 +417,16 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
   }
   __syncthreads();
   const double gl = scal[0], gu = scal[1], pivmin = scal[2];
-  const double h0 = (gu - gl) * (1.0 / (double)(NTB + 1));
-  cnts[t] = trd_sturm(dd2, fma(h0, (double)(t + 1), gl), pivmin);
+  const double h0 = (gu - gl) * (1.0 / (double)(NPT + 1));
+  for (int i = t; i < NPT; i += NTB) cnts[i] = trd_sturm(dd2, fma(h0, (double)(i + 1), gl), pivmin);
   __syncthreads();
   const int r = cq * (NTB / 4) + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
-  int first = 0;  // smallest point index whose count exceeds jidx (NTB: none) -- counts are non-decreasing
-  for (int step = NTB / 2; step > 0; step >>= 1)
-    if (first + step <= NTB && cnts[first + step - 1] <= jidx) first += step;
-  if (first < NTB && cnts[first] <= jidx) first += 1;
+  int first = 0;  // smallest point index whose count exceeds jidx (NPT: none) -- counts are non-decreasing
+  for (int step = NPT / 2; step > 0; step >>= 1)
+    if (first + step <= NPT && cnts[first + step - 1] <= jidx) first += step;
+  if (first < NPT && cnts[first] <= jidx) first += 1;
   lo = first == 0 ? gl : fma(h0, (double)first, gl);
-  hi = first >= NTB ? gu : fma(h0, (double)(first + 1), gl);
+  hi = first >= NPT ? gu : fma(h0, (double)(first + 1), gl);
   for (int it = 0; it < PASSES; ++it) {
     const double h = (hi - lo) * 0.2;
     const double x = fma(h, (double)(s + 1), lo);
