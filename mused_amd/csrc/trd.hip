@@ -21,12 +21,14 @@
 // blocks (a == b) hold BOTH triangles at HALF weight: then  y = A v  is  y_i = sum_j H_ij v_j (row part) + sum_i H_ij v_i
 // (column part) with one uniform expression for every stored element, and the rank-2 update needs no masks either.
 #include <math.h>
+#include <stdlib.h>
 
 #include "internal.h"
 #include "wave_ops.h"
 
 namespace mused {
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int TN = 256, TM = 128, TNT = 512;
 // LDS map (doubles): persistent part, then a scratch region reused by the phases
 constexpr int L_D = 0, L_E = 256, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280, L_MISC = 1536, L_S = 1728;
@@ -309,7 +311,8 @@ constexpr long W_PV = W_ZG + (long)TN * TM;     // forward pivots [256][128], th
 constexpr long W_TG = W_PV + 2l * TN * TM;      // d[256], e[256], tau[256]
 constexpr long W_LG = W_TG + 3 * TN;            // lam[128], 1 / |z| [128], residual / |T| [128]
 constexpr long W_MI = W_LG + 3 * TM;            // {|T|, pivmin, bad flag (int), ...}
-constexpr long W_PER = W_MI + 16;
+constexpr long W_TM = W_MI + 16;                // 16 blocks x (16 x 16) triangular factors of the blocked reflectors
+constexpr long W_PER = W_TM + 16 * 256;
 
 struct TrdDebug {
   long long* clk;            // TRD_STEP_PROFILE: batch x 16, cycles per part of a phase-A step in [8 .. 13]
@@ -586,8 +589,8 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
   }
 }
 
-// ================= kernel D: certificate, then V = Q Z, columns written as lam_j v_j =================
-__global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
+// ================= kernel D (vector-ALU variant, MUSED_TRD_BACK=valu): certificate, then V = Q Z =================
+__global__ __launch_bounds__(TNT, 1) void trd_d_valu_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
                                                        int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
@@ -711,6 +714,187 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
   }
 }
 
+// ================= kernel T: triangular factors of the blocked reflectors =================
+// Reflectors k0 .. k0 + 15 (k0 = 16 kb) as one block:  H_k0 ... H_k0+15 = I - V T V^T  with T upper triangular (LAPACK dlarft,
+// forward / columnwise):  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i).  One workgroup of 256 threads per block.
+__global__ __launch_bounds__(256) void trd_t_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+  __shared__ double Gs[16][17];
+  __shared__ double Ts[16][17];
+  const int bm = blockIdx.x >> 4, kb = blockIdx.x & 15;
+  if (rep && rep[bm] != bm) return;
+  double* wsm = ws + (long)bm * W_PER;
+  const double* Hs = wsm + W_HS;
+  const int t = threadIdx.x, i = t >> 4, j = t & 15;
+  const int ki = 16 * kb + i, kj = 16 * kb + j;
+  double g = 0.0;
+  if (ki <= TN - 3 && kj <= TN - 3) {
+    const double* vi = Hs + (long)ki * TN;
+    const double* vj = Hs + (long)kj * TN;
+    const int r0 = (ki > kj ? ki : kj) + 1;  // both vectors vanish above
+    for (int r = r0; r < TN; ++r) g = fma(vi[r], vj[r], g);
+  }
+  Gs[i][j] = g;
+  Ts[i][j] = 0.0;
+  __syncthreads();
+  for (int c = 0; c < 16; ++c) {  // column c of T
+    const int kc = 16 * kb + c;
+    const double tau = kc <= TN - 3 ? wsm[W_TG + 2 * TN + kc] : 0.0;
+    if (j == 0) {
+      if (i == c) Ts[i][c] = tau;
+      else if (i < c) {
+        double acc = 0.0;
+        for (int b = i; b < c; ++b) acc = fma(Ts[i][b], Gs[b][c], acc);
+        Ts[i][c] = -tau * acc;
+      }
+    }
+    __syncthreads();
+  }
+  wsm[W_TM + kb * 256 + i * 16 + j] = Ts[i][j];
+}
+
+// ================= kernel D: certificate, then V = Q Z on the matrix cores, columns written as lam_j v_j =================
+// The back-transformation is a contraction -- Z (256 x 128) <- (I - V T V^T) Z per block of 16 reflectors: S = V^T Z, C = T S,
+// Z -= V C -- and v_mfma_f64_16x16x4_f64 fits it exactly.  Wave w owns the 16 columns 16 w .. 16 w + 15 of Z as 16 tiles of
+// 16 x 16 in the C / D layout of the instruction (lane (kq, li), register r: row 16 T + kq + 4 r, column li): register r of
+// a tile is at the same time the B operand of the K-slice of rows 16 T + 4 r .. 4 r + 3, so S needs no data movement, and
+// the same holds for S in C = T S and for C in Z -= V C.  The A operands (V^T, T, V) come from LDS, one 8-byte read per
+// lane and MFMA, from two copies of the reflector block laid out for conflict-free reads ([row][reflector] for V^T,
+// [reflector][row], pitch 272, for V).  No cross-wave reduction, two barriers per block of 16 reflectors (staging).
+constexpr int DM_VA = 0;                 // [256][16]   V as [row][reflector]
+constexpr int DM_VB = 4096;              // [16][272]   V as [reflector][row]
+constexpr int DM_TM = DM_VB + 16 * 272;  // [16][16]    T
+constexpr int DM_TOTAL = DM_TM + 256;
+__global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
+                                                       int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int bm = blockIdx.x;
+  if (rep && rep[bm] != bm) {  // (the Jacobi skips it too)
+    if (threadIdx.x == 0) done[bm] = 1;
+    return;
+  }
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int kq = l >> 4, li = l & 15;
+  double* G = Gc + (long)bm * TN * TN;
+  double* wsm = ws + (long)bm * W_PER;
+  const double* Hs = wsm + W_HS;
+  const double* Zg = wsm + W_ZG;
+  double* S = sm + L_S;
+  int* badflag = reinterpret_cast<int*>(sm + L_MISC + 8);
+  if (t < TM) {
+    sm[L_LAM + t] = wsm[W_LG + t];
+    sm[L_ZS + t] = wsm[W_LG + TM + t];
+  }
+  if (t == 0) *badflag = reinterpret_cast<const int*>(wsm + W_MI + 2)[0];
+  __syncthreads();
+  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1];
+  const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
+  auto significant = [&](int c) -> bool { const double lc = sm[L_LAM + c]; return lc > 0.0 && (lc - lamcut) > sigtol; };
+  // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
+  {
+    const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
+    if (c2 < TM && significant(c) && significant(c2)) {
+      double dotv = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
+      if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= 1e-8)) atomicOr(badflag, 2);
+    }
+    if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5) &&
+        (sm[L_LAM + c] - sm[L_LAM + c + 5]) <= 1e-7 * lam0)
+      atomicOr(badflag, 4);
+  }
+  __syncthreads();
+  if (*badflag) {  // leave G as it is: the Jacobi solver takes this matrix
+    if (t == 0) done[bm] = 0;
+    return;
+  }
+  // Z tiles of this wave: column 16 w + li, rows 16 T + kq + 4 r
+  const int col = 16 * w + li;
+  v4f64 Zt[16];
+  {
+    const double zs = sm[L_ZS + col];
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Zt[T][r] = Zg[(long)(16 * T + kq + 4 * r) * TM + col] * zs;
+  }
+  double* vA = S + DM_VA;
+  double* vB = S + DM_VB;
+  double* tm = S + DM_TM;
+  // staging of a block: 16 reflectors x 256 rows = 8 values per thread (coalesced along the row), T: 256 values
+  auto fetch = [&](int kb, double (&nx)[8], double& tx) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int idx = t + TNT * m, kr = 16 * kb + (idx >> 8);
+      nx[m] = (kb >= 0 && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
+    }
+    tx = (kb >= 0 && t < 256) ? wsm[W_TM + kb * 256 + t] : 0.0;
+  };
+  auto store = [&](const double (&nx)[8], double tx) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int idx = t + TNT * m, rr = idx >> 8, row = idx & 255;
+      vA[row * 16 + rr] = nx[m];
+      vB[rr * 272 + row] = nx[m];
+    }
+    if (t < 256) tm[t] = tx;
+  };
+  double nx[8], tx;
+  const int kb_top = (TN - 3) >> 4;
+  fetch(kb_top, nx, tx);
+  store(nx, tx);
+  __syncthreads();
+  for (int kb = kb_top; kb >= 0; --kb) {
+    fetch(kb - 1, nx, tx);
+    const int Tlo = (16 * kb + 1) >> 4;  // row tiles below hold no entry of these reflectors
+    // S = V^T Z_w : M = reflector, K = row, N = column
+    v4f64 Sa = {0.0, 0.0, 0.0, 0.0}, Sb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+      if (T >= Tlo) {  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double a = vA[(16 * T + 4 * r + kq) * 16 + li];  // A[m = li][k = kq] = V[row][reflector li]
+          if (T & 1) Sb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zt[T][r], Sb, 0, 0, 0);
+          else Sa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zt[T][r], Sa, 0, 0, 0);
+        }
+      }
+    }
+    v4f64 Sw = Sa + Sb;
+    // C = T S : M = reflector i, K = reflector j, N = column; then negated for the update
+    v4f64 Cw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) Cw = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[li * 16 + 4 * s4 + kq], Sw[s4], Cw, 0, 0, 0);
+    Cw = -Cw;
+    // Z_tile -= V_tile C : M = row, K = reflector, N = column
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+      if (T >= Tlo) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          Zt[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(vB[(4 * s4 + kq) * 272 + 16 * T + li], Cw[s4], Zt[T], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave is done with this block's LDS copies
+    store(nx, tx);
+    __syncthreads();
+  }
+  {
+    const double lc = sm[L_LAM + col];
+    const double f = lc > 0.0 ? lc : 0.0;
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        G[(long)col * TN + 16 * T + kq + 4 * r] = f * Zt[T][r];
+        G[(long)(col + TM) * TN + 16 * T + kq + 4 * r] = 0.0;
+      }
+  }
+  if (t == 0) {
+    done[bm] = 1;
+    if (dbg.work) atomicAdd(dbg.work, 1ull);
+  }
+}
+
 }  // namespace mused
 
 namespace mused {
@@ -718,13 +902,16 @@ namespace mused {
 size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; }
 
 constexpr int L_A_TOTAL = L_S + 2312;            // kernel A: persistent part + its scratch
-constexpr int L_D_TOTAL = L_S + D_SP + 2 * 2 * 32 * D_SPQ;  // kernel D: reflector blocks + partial sums
+constexpr int L_D_TOTAL = L_S + D_SP + 2 * 2 * 32 * D_SPQ;  // kernel D (vector-ALU variant): reflector blocks + partial sums
+constexpr int L_DM_TOTAL = L_S + DM_TOTAL;                  // kernel D (matrix-core variant)
 
 int trd_prepare() {
   static std::once_flag once;
   static hipError_t rc = hipSuccess;
   std::call_once(once, [] {
-    rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_D_TOTAL));
+    rc = hipFuncSetAttribute((const void*)trd_d_valu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_D_TOTAL));
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_DM_TOTAL));
   });
   MUSED_CHECK_HIP(rc);
   return MUSED_OK;
@@ -740,7 +927,16 @@ int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipS
   if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(4 * batch), dim3(128), 0, st, rep, ws);
   else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws);
   hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), 0, st, rep, ws);
-  hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_D_TOTAL, st, Gc, rep, done, ws, dbg);
+  static const bool back_valu = [] {
+    const char* e = getenv("MUSED_TRD_BACK");
+    return e && e[0] == 'v';
+  }();
+  if (back_valu) {
+    hipLaunchKernelGGL(trd_d_valu_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_D_TOTAL, st, Gc, rep, done, ws, dbg);
+  } else {
+    hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(256), 0, st, rep, ws);
+    hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg);
+  }
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }
