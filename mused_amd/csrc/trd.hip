@@ -716,40 +716,52 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_valu_kernel(double* __restrict__
 
 // ================= kernel T: triangular factors of the blocked reflectors =================
 // Reflectors k0 .. k0 + 15 (k0 = 16 kb) as one block:  H_k0 ... H_k0+15 = I - V T V^T  with T upper triangular (LAPACK dlarft,
-// forward / columnwise):  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i).  One workgroup of 256 threads per block.
-__global__ __launch_bounds__(256) void trd_t_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+// forward / columnwise):  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i).  One wave per block: V^T V by 64 MFMAs
+// (both operands of an instruction are the same register: lane (kq, li) holds V[row 4 s + kq][reflector li]), then the
+// 16 columns of T one after the other, row i on lane i.
+__global__ __launch_bounds__(64) void trd_t_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
   __shared__ double Gs[16][17];
   __shared__ double Ts[16][17];
   const int bm = blockIdx.x >> 4, kb = blockIdx.x & 15;
   if (rep && rep[bm] != bm) return;
   double* wsm = ws + (long)bm * W_PER;
   const double* Hs = wsm + W_HS;
-  const int t = threadIdx.x, i = t >> 4, j = t & 15;
-  const int ki = 16 * kb + i, kj = 16 * kb + j;
-  double g = 0.0;
-  if (ki <= TN - 3 && kj <= TN - 3) {
-    const double* vi = Hs + (long)ki * TN;
-    const double* vj = Hs + (long)kj * TN;
-    const int r0 = (ki > kj ? ki : kj) + 1;  // both vectors vanish above
-    for (int r = r0; r < TN; ++r) g = fma(vi[r], vj[r], g);
+  const int l = threadIdx.x, kq = l >> 4, li = l & 15;
+  const int kr = 16 * kb + li;
+  const double* vrow = Hs + (long)(kr <= TN - 3 ? kr : 0) * TN;
+  const bool okr = kr <= TN - 3;
+  v4f64 Ga = {0.0, 0.0, 0.0, 0.0}, Gb = {0.0, 0.0, 0.0, 0.0};
+  const int s_lo = (16 * kb) >> 2;  // rows below 16 kb hold no entry of these reflectors
+  for (int s4 = s_lo; s4 < TN / 4; s4 += 2) {
+    const double a0 = okr ? vrow[4 * s4 + kq] : 0.0;
+    const double a1 = okr ? vrow[4 * s4 + 4 + kq] : 0.0;
+    Ga = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Ga, 0, 0, 0);
+    Gb = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Gb, 0, 0, 0);
   }
-  Gs[i][j] = g;
-  Ts[i][j] = 0.0;
+  Ga += Gb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Gs[kq + 4 * r][li] = Ga[r];
+    Ts[kq + 4 * r][li] = 0.0;
+  }
   __syncthreads();
-  for (int c = 0; c < 16; ++c) {  // column c of T
-    const int kc = 16 * kb + c;
-    const double tau = kc <= TN - 3 ? wsm[W_TG + 2 * TN + kc] : 0.0;
-    if (j == 0) {
-      if (i == c) Ts[i][c] = tau;
-      else if (i < c) {
+  if (l < 16) {  // row i = l of T, column after column (column c only needs the columns before it)
+    for (int c = 0; c < 16; ++c) {
+      const int kc = 16 * kb + c;
+      const double tau = kc <= TN - 3 ? wsm[W_TG + 2 * TN + kc] : 0.0;
+      double v = 0.0;
+      if (l == c) v = tau;
+      else if (l < c) {
         double acc = 0.0;
-        for (int b = i; b < c; ++b) acc = fma(Ts[i][b], Gs[b][c], acc);
-        Ts[i][c] = -tau * acc;
+        for (int b2 = l; b2 < c; ++b2) acc = fma(Ts[l][b2], Gs[b2][c], acc);
+        v = -tau * acc;
       }
+      Ts[l][c] = v;  // (only this lane reads row l)
     }
-    __syncthreads();
   }
-  wsm[W_TM + kb * 256 + i * 16 + j] = Ts[i][j];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wsm[W_TM + kb * 256 + (kq + 4 * r) * 16 + li] = Ts[kq + 4 * r][li];
 }
 
 // ================= kernel D: certificate, then V = Q Z on the matrix cores, columns written as lam_j v_j =================
@@ -934,7 +946,7 @@ int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipS
   if (back_valu) {
     hipLaunchKernelGGL(trd_d_valu_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_D_TOTAL, st, Gc, rep, done, ws, dbg);
   } else {
-    hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(256), 0, st, rep, ws);
+    hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(64), 0, st, rep, ws);
     hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg);
   }
   MUSED_LAUNCH_CHECK();
