@@ -217,18 +217,64 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
   TRD_TICK(5);
 }
 
-// number of eigenvalues of T below x (negative pivots of the LDL^T of T - x I); dd2[i] = {d_i, e_{i-1}^2}
-__device__ __forceinline__ int trd_sturm(const double2* __restrict__ dd2, double x, double pivmin) {
-  double qv = dd2[0].x - x;
-  if (fabs(qv) < pivmin) qv = -pivmin;
-  int cnt = qv < 0.0 ? 1 : 0;
-#pragma unroll 8
-  for (int i = 1; i < TN; ++i) {
-    const double2 de = dd2[i];
-    qv = fma(-de.y, trd_rcp1(qv), de.x - x);
-    if (fabs(qv) < pivmin) qv = -pivmin;
-    cnt += qv < 0.0 ? 1 : 0;
+// Number of eigenvalues of T below x without a division: the sign changes of the leading principal minors
+//   p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},   p_{-1} = 1, p_0 = d_0 - x
+// (p_i / p_{i-1} is the pivot q_i of the LDL^T of T - x I: a sign change is a negative pivot; the dependent chain per row is
+// ONE fma instead of a reciprocal, its Newton step and an fma).  dd2[i] = {d_i, e_{i-1}^2} of T SCALED by a power of two to
+// |T| in [1/2, 1) with e^2 floored at 2^-120 (an absolute perturbation of 2^-60 |T| of an off-diagonal entry, far below the
+// reduction's own error): then |d_i - x| <= 2 and e^2 <= 1, a minor grows by at most 3 x per row, a pair of consecutive
+// minors shrinks by at most 2^-120 per two rows from the floor (both never vanish: e^2 > 0) and 2^-53 per row from
+// cancellation, and rescaling the pair by the power of two of its larger member every 8 rows keeps it within 2^(+-910) of 1.  An exact zero minor counts once with its successor (whose
+// sign is then -sign of its predecessor): the same count as LAPACK's "zero pivot = negative pivot".  The sign changes go
+// through a shift register of sign bits (one v_alignbit per row) that is emptied by a population count every 24 rows.
+__device__ __forceinline__ int trd_sturm(const double2* __restrict__ dd2, double x) {
+  double p0 = 1.0, p1 = dd2[0].x - x;
+  unsigned bits = (unsigned)__double2hiint(p1) >> 31;  // shift register of the minors' sign bits, newest in bit 0
+  int cnt = (int)bits;                                  // (p_{-1} = 1 > 0)
+  auto row = [&](const double2 de) {
+    const double p2 = fma(de.x - x, p1, -(de.y * p0));
+    bits = __builtin_amdgcn_alignbit(bits, (unsigned)__double2hiint(p2), 31);  // (bits << 1) | sign(p2)
+    p0 = p1;
+    p1 = p2;
+  };
+  auto rescale = [&]() {  // both minors times 2^(1023 - larger biased exponent): integer field arithmetic + two multiplications
+    const unsigned e1 = __builtin_amdgcn_ubfe((unsigned)__double2hiint(p1), 20, 11), e0 = __builtin_amdgcn_ubfe((unsigned)__double2hiint(p0), 20, 11);
+    const double f = __hiloint2double((int)((2046u - max(e1, e0)) << 20), 0);  // (a zero minor has field 0: the other one decides)
+    p1 *= f;
+    p0 *= f;
+  };
+  auto flush = [&](unsigned mask) {  // sign changes among the rows shifted in since the last flush (bit 0 stays as "previous sign")
+    cnt += __builtin_popcount((bits ^ (bits >> 1)) & mask);
+    bits &= 1u;
+  };
+  // rows 1 .. 248 in 31 blocks of 8 (one rescale each), the next block's entries loaded before the current block's chain
+  // (dd2 has 8 spare entries behind row 255), then rows 249 .. 255
+  double2 cur[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cur[j] = dd2[1 + j];
+#pragma unroll 3
+  for (int b = 0; b < 30; ++b) {
+    double2 nxt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nxt[j] = dd2[9 + 8 * b + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) row(cur[j]);
+    rescale();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+    if (b % 3 == 2) flush(0x00ffffffu);  // 24 rows: bits 0 .. 23 against bits 1 .. 24
   }
+  {
+    double2 nxt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nxt[j] = dd2[249 + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) row(cur[j]);  // rows 241 .. 248
+    rescale();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) row(nxt[j]);  // rows 249 .. 255
+  }
+  flush(0x00007fffu);  // 15 rows
   return cnt;
 }
 
@@ -377,7 +423,7 @@ template <int NTB>
 __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
   constexpr int NCH = TNT / NTB, NWV = NTB / 64;
   constexpr int PASSES = 19, NPT = 512;  // 5^19 x 513 > 2^53
-  __shared__ __attribute__((aligned(16))) double2 dd2[TN];
+  __shared__ __attribute__((aligned(16))) double2 dd2[TN + 8];
   __shared__ double part[3 * NWV];
   __shared__ double scal[4];
   __shared__ int cnts[NPT];
@@ -390,7 +436,6 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
   double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308, e2m = 0.0;
   for (int i = t; i < TN; i += NTB) {
     const double di = dg[i], em = i > 0 ? eg[i - 1] : 0.0, ep = eg[i];
-    dd2[i] = make_double2(di, em * em);
     const double rad = fabs(em) + fabs(ep);
     lo = fmin(lo, di - rad);
     hi = fmax(hi, di + rad);
@@ -408,10 +453,13 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
     for (int ww = 1; ww < NWV; ++ww) { lo = fmin(lo, part[3 * ww]); hi = fmax(hi, part[3 * ww + 1]); e2m = fmax(e2m, part[3 * ww + 2]); }
     const double tn = fmax(fabs(lo), fabs(hi));
     const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
-    scal[0] = lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv;
-    scal[1] = hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv;
-    scal[2] = piv;
-    scal[3] = tn;
+    // power-of-two scale that brings |T| (Gershgorin) into [1/2, 1): exact, the eigenvalues are scaled back at the end
+    const int ks = (tn > 0.0 && tn < 1.7976931348623157e308) ? __builtin_amdgcn_frexp_exp(tn) : 0;
+    const double sc = __builtin_amdgcn_ldexp(1.0, -ks);
+    scal[0] = (lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv) * sc;
+    scal[1] = (hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv) * sc;
+    scal[2] = sc;
+    scal[3] = __builtin_amdgcn_ldexp(1.0, ks);
     if (cq == 0) {
       wsm[W_MI] = tn;
       wsm[W_MI + 1] = piv;
@@ -419,9 +467,15 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
     }
   }
   __syncthreads();
-  const double gl = scal[0], gu = scal[1], pivmin = scal[2];
+  const double gl = scal[0], gu = scal[1], sc = scal[2], unsc = scal[3];
+  for (int i = t; i < TN; i += NTB) {
+    const double es_ = (i > 0 ? eg[i - 1] : 0.0) * sc;
+    dd2[i] = make_double2(dg[i] * sc, fmax(es_ * es_, 7.52316384526264e-37));  // 2^-120
+  }
+  if (t < 8) dd2[TN + t] = make_double2(0.0, 0.0);  // (read ahead by the row loop, never used)
+  __syncthreads();
   const double h0 = (gu - gl) * (1.0 / (double)(NPT + 1));
-  for (int i = t; i < NPT; i += NTB) cnts[i] = trd_sturm(dd2, fma(h0, (double)(i + 1), gl), pivmin);
+  for (int i = t; i < NPT; i += NTB) cnts[i] = trd_sturm(dd2, fma(h0, (double)(i + 1), gl));
   __syncthreads();
   const int r = cq * (NTB / 4) + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
   int first = 0;  // smallest point index whose count exceeds jidx (NPT: none) -- counts are non-decreasing
@@ -433,7 +487,7 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
   for (int it = 0; it < PASSES; ++it) {
     const double h = (hi - lo) * 0.2;
     const double x = fma(h, (double)(s + 1), lo);
-    const int above = trd_sturm(dd2, x, pivmin) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
+    const int above = trd_sturm(dd2, x) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
     int nf = above;
     nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR1, 0xf, 0xf, false);
     nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR2, 0xf, 0xf, false);
@@ -441,7 +495,7 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
     hi = (nf == 4) ? hi : fma(h, (double)(nf + 1), lo);
     lo = nlo;
   }
-  if (s == 0) wsm[W_LG + r] = 0.5 * (lo + hi);
+  if (s == 0) wsm[W_LG + r] = 0.5 * (lo + hi) * unsc;
 }
 
 // ================= kernel C: eigenvectors of T by twisted factorisation, 32 per workgroup =================
