@@ -47,14 +47,14 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration `metric` is quoted on
-    "c2": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=10,
+    "c2": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=20,
                name="synthetic d=1024 l=128 window=10000 k=50 (BASELINE config 2)"),
     # BASELINE.json configs[2]
     "c3": dict(W=10000, dims=(4096,), ell=256, k=50, lanes=4,
                name="synthetic d=4096 l=256 window=10000 k=50 (BASELINE config 3)"),
     # BASELINE.json configs[3]: two 512-d modalities -> two kNN adjacencies -> OR-fusion (reference semantics,
     # main.py:45-56); the feature-row sketch sees the 1024-d concatenated rows
-    "c4": dict(W=10000, dims=(512, 512), ell=128, k=50, lanes=10,
+    "c4": dict(W=10000, dims=(512, 512), ell=128, k=50, lanes=20,
                name="synthetic two modalities d=512+512 l=128 window=10000 k=50 (BASELINE config 4)"),
     # small plumbing case (configs[0] shapes) for quick checks
     "c1": dict(W=500, dims=(64,), ell=16, k=50, lanes=4, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
