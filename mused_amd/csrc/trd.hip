@@ -353,8 +353,7 @@ __device__ __forceinline__ void trd_block_update(double (&Z)[16][4], const doubl
 // ---- workspace per matrix (doubles) --------------------------------------------------------------------------------
 constexpr long W_HS = 0;                        // 256 x 256 Householder vectors (row k = v_k)
 constexpr long W_ZG = W_HS + (long)TN * TN;     // 256 x 128 eigenvectors of T, unnormalised ([i][c])
-constexpr long W_PV = W_ZG + (long)TN * TM;     // forward pivots [256][128], then backward pivots [256][128]
-constexpr long W_TG = W_PV + 2l * TN * TM;      // d[256], e[256], tau[256]
+constexpr long W_TG = W_ZG + (long)TN * TM;     // d[256], e[256], tau[256]
 constexpr long W_LG = W_TG + 3 * TN;            // lam[128], 1 / |z| [128], residual / |T| [128]
 constexpr long W_MI = W_LG + 3 * TM;            // {|T|, pivmin, bad flag (int), ...}
 constexpr long W_TM = W_MI + 16;                // 16 blocks x (16 x 16) triangular factors of the blocked reflectors
@@ -501,20 +500,20 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
 // ================= kernel C: eigenvectors of T by twisted factorisation, 32 per workgroup =================
 // Two waves: wave 0 runs the forward pivots and the part of each vector above its twist index, wave 1 the backward pivots
 // and the part below (two dependent chains of 255 divisions side by side); lane c < 32 of either wave = vector cq * 32 + c.
-// The pivot sequences live in global scratch ([i][vector]: a wave's store / load of one i is one 256-byte segment), every
-// stretch of a dependent chain is preceded by its batch of loads: the kernel is latency bound and small (128 threads, 7 KB
-// of LDS), so several of its workgroups share a CU.
+// The pivot sequences of the 32 vectors stay in LDS ([i][vector], 2 x 64 KB: one workgroup per CU); every stretch of a
+// dependent chain is preceded by its batch of loads.
 __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) double2 dd2[TN];
-  __shared__ double es[TN];
-  __shared__ double xch[32 * 4];
+  extern __shared__ __attribute__((aligned(16))) double smc[];  // C_LDS doubles
+  double2* dd2 = reinterpret_cast<double2*>(smc);  // [TN]
+  double* es = smc + 2 * TN;                       // [TN]
+  double* xch = es + TN;                           // [32 * 4]
+  double* qp = xch + 128;                          // forward pivots [TN][32]
+  double* qm = qp + TN * 32;                       // backward pivots [TN][32]
   const int bm = blockIdx.x >> 2, cq = blockIdx.x & 3;
   if (rep && rep[bm] != bm) return;
   const int t = threadIdx.x, role = t >> 6, l = t & 63;
   double* wsm = ws + (long)bm * W_PER;
   double* Zg = wsm + W_ZG;
-  double* qp = wsm + W_PV;
-  double* qm = wsm + W_PV + (long)TN * TM;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int i = t + 128 * h;
@@ -526,13 +525,13 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
   const double tnorm = wsm[W_MI], pivmin = wsm[W_MI + 1];
   const double lam0 = wsm[W_LG], lamcut = wsm[W_LG + TM - 1];
   const bool act = l < 32;
-  const int cl = l & 31, c = cq * 32 + cl;
+  const int cl = l & 31, c = cq * 32 + cl;  // (pivot arrays: column cl of this workgroup's 32)
   const double lam = wsm[W_LG + c];
   auto guard = [&](double v) -> double { return fabs(v) < pivmin ? -pivmin : v; };
   if (act) {
     if (role == 0) {
       double qv = dd2[0].x - lam;
-      qp[c] = qv;
+      qp[cl] = qv;
       for (int i0 = 1; i0 < TN; i0 += 5) {  // 255 = 51 x 5
         double2 de[5];
 #pragma unroll
@@ -540,12 +539,12 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           qv = fma(-de[j].y, trd_rcp(guard(qv)), de[j].x - lam);
-          qp[(long)(i0 + j) * TM + c] = qv;
+          qp[(i0 + j) * 32 + cl] = qv;
         }
       }
     } else {
       double qv = dd2[TN - 1].x - lam;
-      qm[(long)(TN - 1) * TM + c] = qv;
+      qm[(TN - 1) * 32 + cl] = qv;
       for (int i0 = TN - 2; i0 >= 0; i0 -= 5) {  // i0, i0 - 1, .. i0 - 4: 254 .. 0
         double dx[5], e2[5];
 #pragma unroll
@@ -556,12 +555,12 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           qv = fma(-e2[j], trd_rcp(guard(qv)), dx[j]);
-          qm[(long)(i0 - j) * TM + c] = qv;
+          qm[(i0 - j) * 32 + cl] = qv;
         }
       }
     }
   }
-  __syncthreads();  // (drains the stores: the other wave reads them)
+  __syncthreads();  // (the other wave reads the pivots)
   if (act) {  // gamma_i = qp_i + qm_i - (d_i - lam): each role scans one half, ties to the smaller index
     const int i0 = role * (TN / 2);
     double best = 1.7976931348623157e308;
@@ -570,8 +569,8 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
       double a[16], b[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        a[j] = qp[(long)(ib + j) * TM + c];
-        b[j] = qm[(long)(ib + j) * TM + c];
+        a[j] = qp[(ib + j) * 32 + cl];
+        b[j] = qm[(ib + j) * 32 + cl];
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int i = ib - j;
-          qq[j] = i >= 0 ? qp[(long)i * TM + c] : 1.0;
+          qq[j] = i >= 0 ? qp[i * 32 + cl] : 1.0;
           ee[j] = i >= 0 ? es[i] : 0.0;
         }
 #pragma unroll
@@ -617,7 +616,7 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int i = ib + j;
-          qq[j] = i < TN ? qm[(long)i * TM + c] : 1.0;
+          qq[j] = i < TN ? qm[i * 32 + cl] : 1.0;
           ee[j] = i < TN ? es[i - 1] : 0.0;
         }
 #pragma unroll
@@ -970,6 +969,7 @@ size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; 
 constexpr int L_A_TOTAL = L_S + 2312;            // kernel A: persistent part + its scratch
 constexpr int L_D_TOTAL = L_S + D_SP + 2 * 2 * 32 * D_SPQ;  // kernel D (vector-ALU variant): reflector blocks + partial sums
 constexpr int L_DM_TOTAL = L_S + DM_TOTAL;                  // kernel D (matrix-core variant)
+constexpr int C_LDS = 2 * TN + TN + 128 + 2 * TN * 32;       // kernel C: T, exchange, the pivot sequences of 32 vectors
 
 int trd_prepare() {
   static std::once_flag once;
@@ -978,6 +978,8 @@ int trd_prepare() {
     rc = hipFuncSetAttribute((const void*)trd_d_valu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_D_TOTAL));
     if (rc == hipSuccess)
       rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_DM_TOTAL));
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)trd_c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * C_LDS));
   });
   MUSED_CHECK_HIP(rc);
   return MUSED_OK;
@@ -992,7 +994,7 @@ int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipS
   hipLaunchKernelGGL(trd_a_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg);
   if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(4 * batch), dim3(128), 0, st, rep, ws);
   else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws);
-  hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), 0, st, rep, ws);
+  hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws);
   static const bool back_valu = [] {
     const char* e = getenv("MUSED_TRD_BACK");
     return e && e[0] == 'v';
