@@ -278,14 +278,14 @@ def run_swfdmc(args, cfg):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     if rank == 0:
-        direct, t_ms, n_launch, solved = pipe.swfd.profile_read_direct()
+        direct, t_ms, n_launch, solved, _ta_ms = pipe.swfd.profile_read_direct()
         lat = np.array(pipe.latencies[n_warm:])
         fl = 4.0 * 256 ** 3 / 3 + 2.0 * 256 * 256 * 128 + 20 * 512 * 255 * 5.0 + 128 * 4.0 * 255 * 6.0
         roof = None
         if direct and n_launch:
             us = 1e3 * t_ms / n_launch
             tfl = (solved / n_launch) * fl / (us * 1e-6) / 1e12
-            roof = {"kernel": "trd_kernel (direct eigensolver of the FD rotation, order 256; see the c2 line)", "bound": "valu",
+            roof = {"kernel": "trd_a .. trd_d kernels (direct eigensolver of the FD rotation, order 256; see the c2 line)", "bound": "valu",
                     "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP64_PEAK_TFLOPS, "traffic": None,
                     "launch_us": us, "launches_timed": n_launch, "matrices_solved_per_launch_avg": solved / n_launch}
         out = np.asarray(pipe.out[n_warm * W:], dtype=np.int64)
@@ -584,62 +584,78 @@ def main():
         flops_per_matrix_launch = (n2 * (n2 - 1) // 2) * (6.0 * n2) / (nb - 1 if n2 <= 256 else nb)
         direct = bool(sketches) and all(r[0] for r in trd_reads)
         if direct:
-            # dominant kernel by time: trd_kernel (csrc/trd.hip), the direct eigensolver of the FD rotation -- one workgroup
-            # (one CU) per Gram matrix of order 256: Householder tridiagonalisation, 128 eigenvalues by multisection on Sturm
-            # counts, their vectors by twisted factorisation, back-transformation.  fp64 VALU, no MFMA: what bounds it is
-            # the dependent steps (4 workgroup barriers per column of the reduction, ~255 columns), not bytes.
+            # dominant kernel by time: trd_a_kernel (csrc/trd.hip), the Householder tridiagonalisation of the direct eigensolver
+            # of the FD rotation -- one workgroup (one CU) per Gram matrix of order 256, the matrix in registers, fp64 vector
+            # ALU; what bounds it is the chain of dependent steps (4 workgroup barriers per column, 254 columns), not bytes.
+            # The solver is a chain of five kernels (trd_a tridiagonalisation, trd_b 128 eigenvalues by multisection on sign
+            # counts, trd_c their vectors by twisted factorisation, trd_t + trd_d back-transformation on the matrix cores):
+            # `roofline` prices trd_a alone on its own HIP-event bracket, `roofline.solve` the whole chain.
             n = n2
             m_top = ell
             flop_solve = {
-                "tridiagonalisation_4n3_3": 4.0 * n ** 3 / 3.0,
-                "back_transformation_2n2m": 2.0 * n * n * m_top,
-                "sturm_counts_20_passes_x_512_points_x_5flop": 20 * 512 * (n - 1) * 5.0,
-                "twisted_factorisation": m_top * 4.0 * (n - 1) * 6.0,
+                "trd_a_tridiagonalisation_4n3_3": 4.0 * n ** 3 / 3.0,
+                "trd_t_trd_d_back_transformation_2n2m_mfma": 2.0 * n * n * m_top,
+                "trd_b_sign_counts_20_per_thread_x_512_threads_x_4flop": 20 * 512 * (n - 1) * 4.0,
+                "trd_c_twisted_factorisation": m_top * 4.0 * (n - 1) * 6.0,
             }
             fl = sum(flop_solve.values())
+            fl_a = flop_solve["trd_a_tridiagonalisation_4n3_3"]
             t_ms = sum(r[1] for r in trd_reads)
             n_launch = sum(r[2] for r in trd_reads)
             solved = sum(r[3] for r in trd_reads)
+            ta_ms = sum(r[4] for r in trd_reads)
             ns = len(sketches)
-            if n_launch and t_ms > 0:
+            if n_launch and t_ms > 0 and ta_ms > 0:
                 launch_us = 1e3 * t_ms / n_launch
+                a_us = 1e3 * ta_ms / n_launch
                 per_launch = solved / n_launch
                 tfl = per_launch * fl / (launch_us * 1e-6) / 1e12
-                tr = None
+                tfl_a = per_launch * fl_a / (a_us * 1e-6) / 1e12
+                tr = tr_a = None
                 try:
                     pmf = newest_profile("r*_pmc_trd.json")
                     if pmf:
                         pm = json.load(open(pmf))
                         tr = pm["traffic_bytes_per_matrix"] * per_launch
+                        tr_a = pm["per_kernel"]["trd_a_kernel"]["traffic_bytes_per_matrix"] * per_launch
                 except Exception:
-                    tr = None
+                    tr = tr_a = None
+                cu_peak = 1e3 * FP64_PEAK_TFLOPS / 256
                 roof = {
-                    "kernel": f"trd_kernel (direct symmetric eigensolver of the FD rotation: one workgroup = one CU per Gram matrix of "
-                              f"order {n}, top {m_top} eigenpairs; fp64 vector ALU, no MFMA), {np.mean([sk.lanes * 2 * sk.L for sk in sketches]):.0f} "
-                              f"matrices per launch of which {per_launch:.1f} are solved (duplicates / frozen sketches skipped), "
-                              f"{ns} independent launch streams",
+                    "kernel": f"trd_a_kernel (Householder tridiagonalisation of the direct symmetric eigensolver of the FD rotation: one "
+                              f"workgroup = one CU per Gram matrix of order {n}, matrix in registers, fp64 vector ALU), "
+                              f"{np.mean([sk.lanes * 2 * sk.L for sk in sketches]):.0f} matrices per launch of which {per_launch:.1f} "
+                              f"are solved (duplicates / frozen sketches skipped), {ns} independent launch streams",
                     "bound": "valu",
-                    "achieved": tfl,
+                    "achieved": tfl_a,
                     "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s",
-                    "frac": tfl / FP64_PEAK_TFLOPS,
-                    "traffic": tr,
-                    "launch_us": launch_us,
+                    "frac": tfl_a / FP64_PEAK_TFLOPS,
+                    "traffic": tr_a,
+                    "launch_us": a_us,
                     "launches_timed": n_launch,
                     "matrices_solved_per_launch_avg": per_launch,
-                    "flop_per_matrix": flop_solve,
-                    "executed_flops_per_launch": per_launch * fl,
-                    "per_cu": {"achieved_gflops": fl / (launch_us * 1e-6) / 1e9, "peak_gflops": 1e3 * FP64_PEAK_TFLOPS / 256,
-                               "frac": fl / (launch_us * 1e-6) / 1e9 / (1e3 * FP64_PEAK_TFLOPS / 256)},
+                    "algorithmic_flops_per_matrix": fl_a,
+                    "executed_flops_per_launch": per_launch * fl_a,
+                    "per_cu": {"achieved_gflops": fl_a / (a_us * 1e-6) / 1e9, "peak_gflops": cu_peak,
+                               "frac": fl_a / (a_us * 1e-6) / 1e9 / cu_peak},
                     "concurrent_launch_streams": ns,
+                    "solve": {
+                        "kernels": "trd_a_kernel -> trd_b_kernel -> trd_c_kernel -> trd_t_kernel -> trd_d_kernel (one HIP-event bracket)",
+                        "launch_us": launch_us, "flop_per_matrix": flop_solve, "achieved": tfl, "frac": tfl / FP64_PEAK_TFLOPS,
+                        "per_cu_frac": fl / (launch_us * 1e-6) / 1e9 / cu_peak, "traffic": tr,
+                    },
                     "note": "`bound`: the contract's enum is hbm | mfma; this kernel is neither -- fp64 VALU work in a chain of "
-                            "dependent, barrier-separated steps (one CU per matrix), priced on the flops of its four phases "
-                            "against the fp64 vector rate of the chip (78.6 TFLOP/s, the same number as the fp64 MFMA peak).  "
+                            "dependent, barrier-separated steps (one CU per matrix), priced on 4 n^3 / 3 flops per matrix against "
+                            "the fp64 vector rate of the chip (78.6 TFLOP/s, the same number as the fp64 MFMA peak).  "
                             "A launch occupies `matrices_solved_per_launch_avg` of the 256 CUs: `per_cu` is what one busy CU "
-                            "reaches.  algorithmic bytes per matrix: 512 KB read (G) + 256 KB written (128 columns).",
+                            "reaches.  `launch_us` is the HIP-event time from the start of the solver chain to the end of "
+                            "trd_a_kernel on its launch stream, with the other streams of the pipeline running beside it (the "
+                            "rocprofv3 average of trd_a_kernel under profiles/ is the same quantity).  Algorithmic bytes per "
+                            "matrix: 256 KB read (lower triangle of G) + 512 KB of Householder vectors written.",
                 }
                 roof_hbm = {
-                    "kernel": "same launches priced on bytes: G read once (512 KB), 128 columns written (256 KB) per matrix",
+                    "kernel": "the whole solver chain priced on bytes: G read once (512 KB), 128 columns written (256 KB) per matrix",
                     "bound": "hbm", "achieved": per_launch * 786432.0 / (launch_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": per_launch * 786432.0 / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "launch_us": launch_us,
                 }

@@ -199,7 +199,8 @@ int mused_swfd_profile(void* handle, int on);
 int mused_swfd_profile_read(void* handle, double* total_ms, long* launches, double* bytes_per_launch);
 /* the same for sketches whose rotations run the direct eigensolver (order 2 l = 256): ms of the trd_kernel launches, their
  * number, matrices they solved; *direct = 0 -> the rotations run the Jacobi, use mused_swfd_profile_read (HOST outputs) */
-int mused_swfd_profile_read_direct(void* handle, double* total_ms, long* launches, double* matrices_solved, int* direct);
+int mused_swfd_profile_read_direct(void* handle, double* total_ms, long* launches, double* matrices_solved, int* direct,
+                                   double* tridiag_ms /* may be NULL: the share of total_ms spent in trd_a_kernel */);
 /* .fit(row) for n_rows rows at once (any batching gives the same sketch) */
 int mused_swfd_append(void* handle, const void* rows, int dtype, long n_rows, long ld, void* stream);
 /* .get(): out_sketch (lanes x sketch_dim x d), out_sigma (lanes x sketch_dim, may be NULL),

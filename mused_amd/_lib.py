@@ -70,7 +70,7 @@ _PROTOS = {
     "mused_swfd_levels": (_i, [_vp]),
     "mused_swfd_profile": (_i, [_vp, _i]),
     "mused_swfd_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
-    "mused_swfd_profile_read_direct": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d), C.POINTER(_i)]),
+    "mused_swfd_profile_read_direct": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d), C.POINTER(_i), C.POINTER(_d)]),
     "mused_swfd_append": (_i, [_vp, _vp, _i, _l, _l, _vp]),
     "mused_swfd_query": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mused_swfd_counters": (_i, [_vp, C.POINTER(_l), C.POINTER(_i)]),

@@ -56,6 +56,7 @@ struct EigPlan {
   int prof_n;
   std::vector<hipEvent_t>* ev0;
   std::vector<hipEvent_t>* ev1;
+  std::vector<hipEvent_t>* evm;  // direct solver: after its first kernel (the tridiagonalisation)
   double* G[2];
   double* V[2];
   hipGraph_t graph;
@@ -1203,9 +1204,11 @@ void eig_plan_destroy(EigPlan* p) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
       (void)hipEventDestroy((*p->ev1)[i]);
+      if (p->evm) (void)hipEventDestroy((*p->evm)[i]);
     }
     delete p->ev0;
     delete p->ev1;
+    delete p->evm;
   }
   delete p;
 }
@@ -1220,9 +1223,11 @@ int eig_plan_profile(EigPlan* p, bool on) {
   if (on && !p->ev0) {
     p->ev0 = new std::vector<hipEvent_t>(2048);
     p->ev1 = new std::vector<hipEvent_t>(2048);
+    if (p->trd) p->evm = new std::vector<hipEvent_t>(2048);
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       MUSED_CHECK_HIP(hipEventCreate(&(*p->ev0)[i]));
       MUSED_CHECK_HIP(hipEventCreate(&(*p->ev1)[i]));
+      if (p->evm) MUSED_CHECK_HIP(hipEventCreate(&(*p->evm)[i]));
     }
   }
   p->prof = on;
@@ -1258,14 +1263,19 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
   return MUSED_OK;
 }
 
-int eig_plan_profile_read_direct(EigPlan* p, double* total_ms, long* launches, double* matrices_solved) {
+int eig_plan_profile_read_direct(EigPlan* p, double* total_ms, long* launches, double* matrices_solved, double* tridiag_ms) {
   *total_ms = 0.0; *launches = 0; *matrices_solved = 0.0;
+  if (tridiag_ms) *tridiag_ms = 0.0;
   if (!p || !p->trd || !p->ev0) return MUSED_OK;
   for (int i = 0; i < p->prof_n; ++i) {
     MUSED_CHECK_HIP(hipEventSynchronize((*p->ev1)[i]));
     float ms = 0.f;
     MUSED_CHECK_HIP(hipEventElapsedTime(&ms, (*p->ev0)[i], (*p->ev1)[i]));
     *total_ms += ms;
+    if (tridiag_ms && p->evm) {
+      MUSED_CHECK_HIP(hipEventElapsedTime(&ms, (*p->ev0)[i], (*p->evm)[i]));
+      *tridiag_ms += ms;
+    }
   }
   *launches = p->prof_n;
   if (p->work) {
@@ -1313,7 +1323,8 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->trd) {
       if (!p->direct) { set_error("eig_plan_run_inplace: the direct solver needs the caller to fill eig_plan_input"); return MUSED_ERR_STATE; }
-      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st, nullptr, rec ? p->work : nullptr);
+      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st, nullptr, rec ? p->work : nullptr,
+                               (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr);
       if (rc) return rc;
       if (rec) {  // the events of a direct-solver plan bracket the direct solver alone (the Jacobi behind it only sees rejects)
         MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));

@@ -77,7 +77,8 @@ int eig_plan_profile(EigPlan* p, bool on);
 int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* bytes_per_launch);
 // plans that run the direct solver: summed ms of its launches (HIP events around the kernel alone), number of launches,
 // matrices it solved over all of them
-int eig_plan_profile_read_direct(EigPlan* p, double* total_ms, long* launches, double* matrices_solved);
+int eig_plan_profile_read_direct(EigPlan* p, double* total_ms, long* launches, double* matrices_solved,
+                                 double* tridiag_ms = nullptr);
 bool eig_plan_direct_solver(EigPlan* p);  // the plan runs the direct solver (trd.hip) with the Jacobi as its fallback
 double* eig_plan_input(EigPlan* p);  // (batch x n x n) device buffer the caller may fill directly
 // Raw result of the one-sided solver (false: not available): cols[(b * ld + j) * ld + a] = lam_j u_j[a],
@@ -89,6 +90,6 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t strea
 size_t trd_workspace_doubles(int batch);
 int trd_prepare();
 int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, long long* dbg_clk = nullptr,
-              unsigned long long* work = nullptr);
+              unsigned long long* work = nullptr, hipEvent_t after_a = nullptr);
 
 }  // namespace mused

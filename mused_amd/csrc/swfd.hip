@@ -773,14 +773,14 @@ int mused_swfd_profile_read(void* handle, double* total_ms, long* launches, doub
 }
 
 // As mused_swfd_profile_read for sketches whose rotations run the direct eigensolver (csrc/trd.hip; order 2 l = 256):
-// summed ms of the trd_kernel launches timed since mused_swfd_profile(handle, 1), their number, and the number of matrices
-// they solved.  *direct = 0: this sketch's rotations run the Jacobi (use mused_swfd_profile_read).  BLOCKING.
+// summed ms of the direct-solver launches (trd_a .. trd_d, five kernels each) timed since mused_swfd_profile(handle, 1), their
+// number, the number of matrices they solved, and (tridiag_ms, may be NULL) the part of that time up to the end of trd_a_kernel.  *direct = 0: this sketch's rotations run the Jacobi (use mused_swfd_profile_read).  BLOCKING.
 extern "C" int mused_swfd_profile_read_direct(void* handle, double* total_ms, long* launches, double* matrices_solved,
-                                              int* direct) {
+                                              int* direct, double* tridiag_ms) {
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && total_ms && launches && matrices_solved && direct, "mused_swfd_profile_read_direct: null pointer");
   *direct = eig_plan_direct_solver(h->eig) ? 1 : 0;
-  return eig_plan_profile_read_direct(h->eig, total_ms, launches, matrices_solved);
+  return eig_plan_profile_read_direct(h->eig, total_ms, launches, matrices_solved, tridiag_ms);
 }
 
 // Replaces the per-row SeqBasedSWFD.fit(row) loop (main.py:65-67): appends n_rows rows of

@@ -989,9 +989,10 @@ int trd_prepare() {
 // lam_j v_j for its 128 largest eigenvalues (descending), columns 128 .. 255 zeros; done[b] = 0 -> untouched (certificate
 // failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.  Four launches on `st`.
 int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, long long* dbg_clk,
-              unsigned long long* work) {
+              unsigned long long* work, hipEvent_t after_a) {
   TrdDebug dbg{dbg_clk, work};
   hipLaunchKernelGGL(trd_a_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg);
+  if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));  // profiling: the tridiagonalisation alone
   if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(4 * batch), dim3(128), 0, st, rep, ws);
   else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws);
   hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws);

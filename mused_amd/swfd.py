@@ -150,11 +150,12 @@ class SeqBasedSWFD:
         return ms.value, n.value, b.value
 
     def profile_read_direct(self):
-        """(direct, summed ms of the direct-eigensolver launches, launches, matrices solved) -- direct False: the rotations
+        """(direct, summed ms of the direct-eigensolver launches, launches, matrices solved, ms of that inside the
+        tridiagonalisation kernel) -- direct False: the rotations
         of this sketch run the Jacobi (order != 256 or MUSED_EIG_TRD=0), use profile_read()."""
-        ms, n, m, d = C.c_double(), C.c_long(), C.c_double(), C.c_int()
-        call("mused_swfd_profile_read_direct", self._h, C.byref(ms), C.byref(n), C.byref(m), C.byref(d))
-        return bool(d.value), ms.value, n.value, m.value
+        ms, n, m, d, ta = C.c_double(), C.c_long(), C.c_double(), C.c_int(), C.c_double()
+        call("mused_swfd_profile_read_direct", self._h, C.byref(ms), C.byref(n), C.byref(m), C.byref(d), C.byref(ta))
+        return bool(d.value), ms.value, n.value, m.value, ta.value
 
     # -- bookkeeping / multi-GPU state exchange ---------------------------------------------------
     @property

@@ -1,0 +1,58 @@
+"""FETCH_SIZE / WRITE_SIZE of the direct eigensolver's kernels (csrc/trd.hip) from two rocprofv3 --pmc passes over
+tools/pmc_trd_run.py -> the JSON bench.py reads (profiles/rNN_pmc_trd.json):
+
+    python tools/pmc_trd_summarise.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <matrices per launch>
+
+Units and the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KB; FETCH_SIZE
+reports half the bytes of wide coalesced streaming reads and is doubled (an upper bound for the kernels whose reads are
+8 bytes per lane), WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mused::", "")
+        if name.startswith("trd_"):
+            acc[name.split("<")[0]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+batch = int(sys.argv[3])
+algorithmic = {
+    "trd_a_kernel": 256 * 257 // 2 * 8 + 254 * 256 * 8,   # lower triangle of G read, Householder vectors written
+    "trd_b_kernel": 3 * 256 * 8 + 128 * 8,                 # d, e read; 128 eigenvalues written
+    "trd_c_kernel": 4 * 2 * 256 * 8 + 256 * 128 * 8,       # d, e read by 4 workgroups; 128 eigenvectors of T written
+    "trd_t_kernel": 254 * 256 * 8 + 16 * 256 * 8,          # Householder vectors read; 16 triangular factors written
+    "trd_d_kernel": 254 * 256 * 8 + 256 * 128 * 8 + 16 * 256 * 8 + 256 * 256 * 8,  # V, Z, T read; 256 columns written
+}
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --output-format csv -- python3 "
+                 f"tools/pmc_trd_run.py {batch}, MI355X (launches of {batch} matrices each)",
+       "matrices_per_launch": batch, "per_kernel": {}}
+tot = 0.0
+for k in sorted(set(fetch) | set(write)):
+    fk = sum(fetch.get(k, [0.0])) / max(1, len(fetch.get(k, [])))
+    wk = sum(write.get(k, [0.0])) / max(1, len(write.get(k, [])))
+    t = (2.0 * fk + wk) * 1024.0 / batch
+    tot += t
+    out["per_kernel"][k] = {"launches": len(fetch.get(k, [])), "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk,
+                            "fetch_bytes_per_matrix_corrected_x2": 2.0 * fk * 1024.0 / batch,
+                            "write_bytes_per_matrix": wk * 1024.0 / batch, "traffic_bytes_per_matrix": t,
+                            "algorithmic_bytes_per_matrix": algorithmic.get(k)}
+out["traffic_bytes_per_matrix"] = tot
+out["algorithmic_bytes_per_matrix_chain"] = 512 * 1024 + 256 * 1024
+out["note"] = ("chain = trd_a -> trd_b -> trd_c -> trd_t -> trd_d; the Householder vectors (512 KB), the eigenvectors of T (256 KB) "
+               "and the triangular factors travel through global scratch between the kernels, the lower half of the output "
+               "(256 KB of zeros) is written too: the chain's traffic is a few times its end-to-end algorithmic bytes (G read, "
+               "128 columns written) and still far below what HBM delivers in the chain's duration -- it is bound by dependent "
+               "steps, not bytes.")
+print(json.dumps(out, indent=1))
