@@ -201,9 +201,12 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
         X64 = X.astype(np.float64)
         R = float((X64**2).sum(1).max())
         sk = OraSWFD(N=W, R=R, d=X.shape[1], sketch_dim=ell)
-        swfd_rows = min(W, 4 * ell)  # 4 rotations of every level; steady-state cost per row is constant
+        # blocks of l rows (one rotation of every level each; the steady-state cost per row is constant) until ~10 s of
+        # CPU time are spent, at least 4 blocks
         ts = time.perf_counter()
-        sk.fit(X64[:swfd_rows])
+        while swfd_rows < W and (swfd_rows < 4 * ell or time.perf_counter() - ts < 10.0):
+            sk.fit(X64[swfd_rows:swfd_rows + ell])
+            swfd_rows = min(W, swfd_rows + ell)
         sk.get()
         t_swfd_per_row = (time.perf_counter() - ts) / swfd_rows
     if limiter is not None:
