@@ -115,6 +115,14 @@ def test_direct_solver_special_matrices_and_certificate():
         "diagonal": np.diag(np.linspace(1, 300, 256)),
         "graded": (Q * np.logspace(0, -12, 256)) @ Q.T,
         "binary": (lambda A: A @ A.T)((rng.random((256, 2000)) < 0.025).astype(float)),
+        # the sign counts run on T scaled by a power of two: the scale of the input must not matter
+        "scaled_up": (lambda B: B @ B.T)(rng.standard_normal((256, 300))) * 1e100,
+        "scaled_down": (lambda B: B @ B.T)(rng.standard_normal((256, 300))) * 1e-100,
+        # Wilkinson W_256^+ (pairs of eigenvalues agreeing to rounding at the top of the spectrum) as the Gram input:
+        # eigenvalues must be right; the certificate may or may not reject the close pairs
+        "wilkinson": np.diag(np.abs(np.arange(256) - 127.5)) + np.diag(np.ones(255), 1) + np.diag(np.ones(255), -1),
+        # tridiagonal with tiny off-diagonals next to equal diagonal entries (zero minors in the sign count)
+        "tiny_offdiag": np.diag(np.repeat(np.arange(1.0, 129.0), 2)) + np.diag(np.full(255, 1e-160), 1) + np.diag(np.full(255, 1e-160), -1),
     }
     names = list(cases)
     Gs = [0.5 * (cases[k] + cases[k].T) for k in names]
@@ -124,7 +132,7 @@ def test_direct_solver_special_matrices_and_certificate():
         w = np.linalg.eigvalsh(G)[::-1]
         scale = max(np.abs(w).max(), 1e-300)
         np.testing.assert_allclose(lam[b], w[:128], rtol=0, atol=1e-13 * scale + 1e-300, err_msg=name)
-        if name == "hundredfold":
+        if name == "hundredfold" or (name in ("wilkinson", "tiny_offdiag") and done[b] == 0):
             assert done[b] == 0, name                      # certificate: clustered eigenvalues go to the Jacobi solver
             assert np.array_equal(out[b], G), name         # ... with their input untouched
             continue
