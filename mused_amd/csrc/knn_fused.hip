@@ -549,28 +549,11 @@ static int knn_fused_t(const T* X, long n, int d, long ld, int k, int metric, co
   }
   int rc;
   int d_lo = 0;
-  static const bool trace = getenv("MUSED_HOP_TRACE") != nullptr;
-  auto dump = [&](const char* what) {
-    if (!trace) return;
-    (void)hipStreamSynchronize(st);
-    std::vector<int> cnt(n);
-    int fl = 0;
-    (void)hipMemcpy(cnt.data(), ws.count, 4 * (size_t)n, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&fl, ws.overflow, 4, hipMemcpyDeviceToHost);
-    int mx = 0, mxi = 0;
-    for (long i = 0; i < n; ++i) if (cnt[i] > mx) { mx = cnt[i]; mxi = (int)i; }
-    fprintf(stderr, "[knn trace] %s: flag %d, max count %d at slot %d (cap %d, hop %d, n_ret %d, kthr %d)\n", what, fl, mx, mxi, cap,
-            (int)hop, c.n_ret, kthr);
-  };
-  dump("start");
   while (true) {
     if (d_hi > hmax) d_hi = hmax;
     if ((rc = band(d_lo, d_hi - d_lo + 1, direct && d_lo == 0))) return rc;
-    if (trace) fprintf(stderr, "[knn trace] band delta %d..%d\n", d_lo, d_hi);
-    dump("after band");
     const bool last = d_hi >= hmax;
     select(last ? 1 : 0);
-    dump("after select");
     if (last) break;
     d_lo = d_hi + 1;
     const long seen = (2l * d_hi + 1) * 128, left = (long)n - seen;
