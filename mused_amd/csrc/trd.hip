@@ -146,38 +146,65 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
 #pragma unroll
         for (int b = K; b <= a; ++b) c[b] = fma(A[u][tidx(a, b)], vi, c[b]);
       }
-    // (4) in-wave transposing reductions: r over the 8 lanes that differ in lq (lane bits 0-2), c over lp (lane bits 3-5)
-    const bool h2 = (l & 4) != 0, h0 = (l & 1) != 0, h1 = (l & 2) != 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {  // partner 7 - (l & 7) of the 8-lane group: decided by bit 2
-      const double keep = h2 ? r[e + 8] : r[e], send = h2 ? r[e] : r[e + 8];
-      r[e] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {  // l ^ 1
-      const double keep = h0 ? r[e + 4] : r[e], send = h0 ? r[e] : r[e + 4];
-      r[e] = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {  // l ^ 2
-      const double keep = h1 ? r[e + 2] : r[e], send = h1 ? r[e] : r[e + 2];
-      r[e] = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send);
-    }
-    const int e0 = (h2 ? 8 : 0) + (h0 ? 4 : 0) + (h1 ? 2 : 0);  // this lane ends with r-values e0, e0 + 1
-    double* rp = S + A_RP + wq * 256;
-    rp[p + 16 * e0] = r[0];
-    rp[p + 16 * (e0 + 1)] = r[1];
+    // (4) in-wave transposing reductions: r (16 values) over the 8 lanes that differ in lq = lane bits 3-5 -- two stages of
+    //     v_permlane{32,16}_swap (3 instructions per pair) and one row rotation --, c (8 values) over lp = lane bits 0-2 by DPP
+    //     (7 instructions per pair: two selects, the move, the add).  From column 128 on (K >= 4) the rows and columns below
+    //     128 are out of the trailing matrix: their sums are zeros and the first stage of either reduction is skipped.
     const bool h5 = (l & 32) != 0, h4 = (l & 16) != 0, h3 = (l & 8) != 0;
+    const bool h2 = (l & 4) != 0, h1 = (l & 2) != 0, h0 = (l & 1) != 0;
+    double* rp = S + A_RP + wq * 256;
+    double* cpw = S + A_CP + wp * 256;
+    if constexpr (K < 4) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) c[b] = swap32_add(c[b], c[b + 4]);   // lanes 0-31 keep b 0-3, lanes 32-63 keep b 4-7
+      for (int e = 0; e < 8; ++e) r[e] = swap32_add(r[e], r[e + 8]);  // lanes 0-31 keep e, lanes 32-63 e + 8
 #pragma unroll
-    for (int b = 0; b < 2; ++b) c[b] = swap16_add(c[b], c[b + 2]);   // bit 4 clear keeps the lower two, set the upper two
-    {
-      const double keep = h3 ? c[1] : c[0], send = h3 ? c[0] : c[1];
-      c[0] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+      for (int e = 0; e < 4; ++e) r[e] = swap16_add(r[e], r[e + 4]);  // bit 4 clear keeps e, set e + 4
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {  // l ^ 8
+        const double keep = h3 ? r[e + 2] : r[e], send = h3 ? r[e] : r[e + 2];
+        r[e] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+      }
+      const int e0 = (h5 ? 8 : 0) + (h4 ? 4 : 0) + (h3 ? 2 : 0);  // this lane ends with r-values e0, e0 + 1
+      rp[p + 16 * e0] = r[0];
+      rp[p + 16 * (e0 + 1)] = r[1];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {  // partner 7 - (l & 7) of the 8-lane group: decided by bit 2
+        const double keep = h2 ? c[b + 4] : c[b], send = h2 ? c[b] : c[b + 4];
+        c[b] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {  // l ^ 1
+        const double keep = h0 ? c[b + 2] : c[b], send = h0 ? c[b] : c[b + 2];
+        c[b] = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send);
+      }
+      {  // l ^ 2
+        const double keep = h1 ? c[1] : c[0], send = h1 ? c[0] : c[1];
+        c[0] = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send);
+      }
+      const int b0 = (h2 ? 4 : 0) + (h0 ? 2 : 0) + (h1 ? 1 : 0);
+      cpw[q + 32 * b0] = c[0];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = swap32_add(r[8 + e], r[12 + e]);  // rows 8 + e (lanes 0-31), 12 + e (lanes 32-63)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) r[e] = swap16_add(r[e], r[e + 2]);
+      {
+        const double keep = h3 ? r[1] : r[0], send = h3 ? r[0] : r[1];
+        r[0] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+      }
+      rp[p + 16 * (8 + (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0))] = r[0];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const double keep = h2 ? c[6 + b] : c[4 + b], send = h2 ? c[4 + b] : c[6 + b];
+        c[b] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+      }
+      {
+        const double keep = h0 ? c[1] : c[0], send = h0 ? c[0] : c[1];
+        c[0] = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send);
+      }
+      c[0] = c[0] + dpp_mov_f64<DPP_QUAD_XOR2>(c[0]);  // (the two lanes of the pair end with the same sum)
+      if (!h1) cpw[q + 32 * (4 + (h2 ? 2 : 0) + (h0 ? 1 : 0))] = c[0];
     }
-    const int b0 = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
-    (S + A_CP + wp * 256)[q + 32 * b0] = c[0];
     dpart = wave_allsum(dpart);
     if (l == 0) S[A_RED + (t >> 6)] = dpart;
   }
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
   const int bm = blockIdx.x;
   if (rep && rep[bm] != bm) return;  // duplicate of another matrix / frozen sketch: nothing to solve
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  const int wp = w >> 2, wq = w & 3, lp = l >> 3, lq = l & 7;
+  const int wp = w >> 2, wq = w & 3, lp = l & 7, lq = l >> 3;  // (lq in the lane bits the v_permlane swaps reach)
   const int p = wp * 8 + lp, q = wq * 8 + lq;
   const double* G = Gc + (long)bm * TN * TN;
   double* wsm = ws + (long)bm * W_PER;
