@@ -33,7 +33,7 @@ constexpr int TN = 256, TM = 128, TNT = 512;
 // LDS map (doubles): persistent part, then a scratch region reused by the phases
 constexpr int L_D = 0, L_E = 256, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280, L_MISC = 1536, L_S = 1728;
 // phase A scratch
-constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][256] */, A_CP = 1792 /* [2][256] */, A_RED = 2304 /* [8] */;
+constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][256] */, A_CP = 1792 /* [2][256] */, A_RED = 2304 /* [8] */, A_SQ = 2312 /* [2] */;
 // phase D scratch
 constexpr int D_VB = 0 /* [2][16][256] */, D_SP = 8192 /* [2][2][32][26] */;
 
@@ -75,25 +75,31 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
   double* xs = S + A_XS;
   double* vs = S + A_VS;
   double* ws = S + A_WS;
-  // (1) column k below the diagonal -> xs (the 16 threads of grid column q == kk hold it)
+  // (1) column k below the diagonal -> xs (the 16 threads of grid column q == kk hold it: 8 adjacent lanes in each of two
+  //     waves), and the sum of squares below row k + 1 from their registers: 8-lane butterfly, one partial per wave
   if (q == kk) {
+    double sqp = 0.0;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int a = K; a < 8; ++a) xs[p + 16 * u + 32 * a] = (a == K ? 2.0 : 1.0) * A[u][tidx(a, K)];
+      for (int a = K; a < 8; ++a) {
+        const int i = p + 16 * u + 32 * a;
+        const double x = (a == K ? 2.0 : 1.0) * A[u][tidx(a, K)];
+        xs[i] = x;
+        if (a <= K + 1) sqp += (i > k + 1) ? x * x : 0.0;  // (row k + 1 lies in block K, or is the first row of block K + 1)
+        else sqp = fma(x, x, sqp);
+      }
+    sqp += dpp_mov_f64<DPP_QUAD_XOR1>(sqp);
+    sqp += dpp_mov_f64<DPP_QUAD_XOR2>(sqp);
+    sqp += dpp_mov_f64<DPP_ROW_HALF_MIRROR>(sqp);
+    if ((l & 7) == 0) S[A_SQ + wp] = sqp;
     if (p == (k & 15)) sm[L_D + k] = 2.0 * ((kk >> 4) ? A[1][tidx(K, K)] : A[0][tidx(K, K)]);
   }
   lds_barrier();
   TRD_TICK(0);
-  // (2) Householder vector (dlarfg), every wave on its own: beta = -sign(x0) |x|, tau = (beta - x0) / beta, v = x / (x0 - beta)
-  double sq = 0.0;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int i = l + 64 * m;
-    const double x = xs[i];
-    sq += (i > k + 1) ? x * x : 0.0;
-  }
-  sq = wave_allsum(sq);
+  // (2) Householder vector (dlarfg), every thread for itself from the two partial sums:
+  //     beta = -sign(x0) |x|, tau = (beta - x0) / beta, v = x / (x0 - beta)
+  const double sq = S[A_SQ] + S[A_SQ + 1];
   const double x0 = xs[k + 1];
   double tau = 0.0, beta = x0, scale = 0.0;
   if (sq > 0.0) {
@@ -993,7 +999,7 @@ namespace mused {
 
 size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; }
 
-constexpr int L_A_TOTAL = L_S + 2312;            // kernel A: persistent part + its scratch
+constexpr int L_A_TOTAL = L_S + 2314;            // kernel A: persistent part + its scratch
 constexpr int L_D_TOTAL = L_S + D_SP + 2 * 2 * 32 * D_SPQ;  // kernel D (vector-ALU variant): reflector blocks + partial sums
 constexpr int L_DM_TOTAL = L_S + DM_TOTAL;                  // kernel D (matrix-core variant)
 constexpr int C_LDS = 2 * TN + TN + 128 + 2 * TN * 32;       // kernel C: T, exchange, the pivot sequences of 32 vectors
