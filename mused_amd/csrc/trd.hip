@@ -486,7 +486,8 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
     const double tn = fmax(fabs(lo), fabs(hi));
     const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
     // power-of-two scale that brings |T| (Gershgorin) into [1/2, 1): exact, the eigenvalues are scaled back at the end
-    const int ks = (tn > 0.0 && tn < 1.7976931348623157e308) ? __builtin_amdgcn_frexp_exp(tn) : 0;
+    int ks = (tn > 0.0 && tn < 1.7976931348623157e308) ? __builtin_amdgcn_frexp_exp(tn) : 0;
+    ks = ks > 1000 ? 1000 : (ks < -1000 ? -1000 : ks);  // (both 2^ks and 2^-ks stay finite)
     const double sc = __builtin_amdgcn_ldexp(1.0, -ks);
     scal[0] = (lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv) * sc;
     scal[1] = (hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv) * sc;
