@@ -70,25 +70,82 @@ constexpr int CHOLQR_MAX_R = 143;  // packed lower triangle of L (r (r + 1) / 2 
 
 __device__ __forceinline__ int tri_at(int i, int k) { return i * (i + 1) / 2 + k; }
 
-// one workgroup: G (r x r, full) -> packed L = chol(G + delta I), written to Lg (r (r + 1) / 2 doubles).  The trailing
-// update of a step is dealt to a 16 x 16 grid of threads (rows i = j + 1 + ti (mod 16), columns k = j + 1 + tk (mod 16)).
-__global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ G, int r, double* __restrict__ Lg,
-                                                   int* __restrict__ weak_flag) {
-  extern __shared__ double cq_smem[];
-  __shared__ double s_red[4];
-  __shared__ double s_delta;
-  const int t = threadIdx.x, ti = t >> 4, tk = t & 15;
-  const int ntri = r * (r + 1) / 2;
-  double* Lp = cq_smem;
-  double dmax = 0.0;
-  for (int e = t; e < r * r; e += 256) {
-    const int i = e / r, k = e - i * r;
-    if (k <= i) {
-      const double v = G[e];
-      Lp[tri_at(i, k)] = v;
-      if (k == i) dmax = fmax(dmax, v);
+// one workgroup: G (r x r, full) -> packed L = chol(G + delta I), written to Lg (r (r + 1) / 2 doubles).
+// The matrix lives in REGISTERS: the lower block triangle is dealt 2-D cyclically to a 16 x 16 thread grid (element
+// (i, k) with i = p + 16 a, k = q + 16 b, a >= b: 45 doubles per thread for r <= 144), as in the tridiagonalisation of
+// trd.hip.  Right-looking, one column per step: the owners of column j put it (raw) into an LDS vector, ONE barrier, every
+// thread forms d = sqrt(pivot), 1 / d (v_rsq_f64 + two Newton steps) and the scaled entries of its 9 rows and 9 columns and
+// applies the rank-1 update to its elements; the vector is double-buffered, so the next column's owners never wait.
+// (The first version worked on a packed triangle in LDS with a rank-8 trailing update per panel: 220 us for r = 138,
+// bound by LDS round trips; this one: see DESIGN section 4e.)
+constexpr int CH_NB = 9;  // 16 x 9 = 144 >= CHOLQR_MAX_R
+static_assert(16 * CH_NB >= CHOLQR_MAX_R, "chol_kernel holds at most 16 * CH_NB rows");
+__host__ __device__ constexpr int ch_tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+template <int B>
+__device__ __forceinline__ void chol_block_columns(double (&A)[CH_NB * (CH_NB + 1) / 2], double (*colbuf)[16 * CH_NB], int r, int t,
+                                                   int p, int q, double delta, double weak, int* __restrict__ weak_flag) {
+  for (int jj = 0; jj < 16; ++jj) {
+    const int j = 16 * B + jj;
+    if (j >= r) return;  // (uniform)
+    double* cb = colbuf[j & 1];
+    if (q == jj) {
+#pragma unroll
+      for (int a = B; a < CH_NB; ++a) {
+        const int i = p + 16 * a;
+        if (i >= j && i < r) cb[i] = A[ch_tri(a, B)];
+      }
+    }
+    __syncthreads();
+    const double piv0 = cb[j];
+    // a pivot below 1e-11 of the largest diagonal entry: Y is (numerically) rank deficient or worse conditioned than 3e5
+    // -- fine for a normaliser, not for the final orthonormal basis (the caller then falls back to Householder QR)
+    if (weak_flag && t == 0 && !(piv0 > weak)) *weak_flag = 1;
+    const double piv = piv0 + delta;
+    const double pc = piv > delta ? piv : delta;
+    double inv = __builtin_amdgcn_rsq(pc);
+    inv = inv * fma(-0.5 * pc, inv * inv, 1.5);
+    inv = inv * fma(-0.5 * pc, inv * inv, 1.5);
+    const double d = pc * inv;
+    double lr[CH_NB], lc[CH_NB];
+#pragma unroll
+    for (int a = B; a < CH_NB; ++a) {
+      const int i = p + 16 * a, k = q + 16 * a;
+      lr[a] = (i > j && i < r) ? cb[i] * inv : 0.0;
+      lc[a] = (k > j && k < r) ? cb[k] * inv : 0.0;
+    }
+#pragma unroll
+    for (int b = B; b < CH_NB; ++b)
+#pragma unroll
+      for (int a = b; a < CH_NB; ++a) A[ch_tri(a, b)] = fma(-lr[a], lc[b], A[ch_tri(a, b)]);
+    if (q == jj) {  // column j of L: d on the diagonal, the scaled entries below (lc[B] = 0 here: the update left them alone)
+#pragma unroll
+      for (int a = B; a < CH_NB; ++a) {
+        const int i = p + 16 * a;
+        if (i > j) A[ch_tri(a, B)] = lr[a];
+        else if (i == j) A[ch_tri(a, B)] = d;
+      }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ G, int r, double* __restrict__ Lg,
+                                                   int* __restrict__ weak_flag) {
+  __shared__ double colbuf[2][16 * CH_NB];
+  __shared__ double s_red[4];
+  __shared__ double s_delta;
+  const int t = threadIdx.x, q = t & 15, p = t >> 4;  // (q fastest: 16 consecutive entries of a row per 16 threads)
+  double A[CH_NB * (CH_NB + 1) / 2];
+  double dmax = 0.0;
+#pragma unroll
+  for (int a = 0; a < CH_NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = p + 16 * a, k = q + 16 * b;
+      const double v = (i < r && k <= i) ? G[(long)i * r + k] : 0.0;
+      A[ch_tri(a, b)] = v;
+      if (k == i && i < r) dmax = fmax(dmax, v);
+    }
   for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
   if ((t & 63) == 0) s_red[t >> 6] = dmax;
   __syncthreads();
@@ -96,54 +153,22 @@ __global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ G,
   __syncthreads();
   const double delta = s_delta;
   const double weak = 1e-11 * (delta / (16.0 * r * 2.220446049250313e-16));
-  // Blocked right-looking factorisation, panels of 8 columns: inside a panel a column step only touches the panel's own
-  // columns; the rest of the matrix gets ONE rank-8 update per panel (8 FMAs per entry and LDS pass instead of 8 passes).
-  for (int jb = 0; jb < r; jb += 8) {
-    const int pw = (r - jb) < 8 ? (r - jb) : 8;
-    for (int p = 0; p < pw; ++p) {
-      const int j = jb + p;
-      const double piv0 = Lp[tri_at(j, j)];  // the same (final) value for every thread
-      // a pivot below 1e-11 of the largest diagonal entry: Y is (numerically) rank deficient or worse conditioned than 3e5
-      // -- fine for a normaliser, not for the final orthonormal basis (the caller then falls back to Householder QR)
-      if (weak_flag && t == 0 && !(piv0 > weak)) *weak_flag = 1;
-      const double piv = piv0 + delta;
-      const double d = sqrt(piv > delta ? piv : delta);
-      const double inv = 1.0 / d;
-      __syncthreads();  // all have read the pivot
-      if (t == 0) Lp[tri_at(j, j)] = d;
-      for (int i = j + 1 + t; i < r; i += 256) Lp[tri_at(i, j)] *= inv;
-      __syncthreads();
-      const int nc = jb + pw - 1 - j;  // panel columns still to be updated by column j
-      if (nc > 0) {
-        const int tot = (r - j - 1) * nc;
-        for (int e = t; e < tot; e += 256) {
-          const int q = e / nc, c = j + 1 + (e - q * nc), i = j + 1 + q;
-          if (i >= c) Lp[tri_at(i, c)] -= Lp[tri_at(i, j)] * Lp[tri_at(c, j)];
-        }
-      }
-      __syncthreads();
-    }
-    const int j1 = jb + pw;
-    for (int i = j1 + ti; i < r; i += 16) {  // rank-pw update of the trailing block, dealt to a 16 x 16 thread grid
-      const double* ri = Lp + tri_at(i, jb);
-      double li[8];
+  chol_block_columns<0>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<1>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<2>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<3>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<4>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<5>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<6>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<7>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
+  chol_block_columns<8>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) li[p] = p < pw ? ri[p] : 0.0;
-      double* row = Lp + tri_at(i, 0);
-      for (int k = j1 + tk; k <= i; k += 16) {
-        const double* rk = Lp + tri_at(k, jb);
-        double s0 = 0.0, s1 = 0.0;
+  for (int a = 0; a < CH_NB; ++a)
 #pragma unroll
-        for (int p = 0; p < 8; p += 2) {
-          if (p < pw) s0 = fma(li[p], rk[p], s0);
-          if (p + 1 < pw) s1 = fma(li[p + 1], rk[p + 1], s1);
-        }
-        row[k] -= s0 + s1;
-      }
+    for (int b = 0; b <= a; ++b) {
+      const int i = p + 16 * a, k = q + 16 * b;
+      if (i < r && k <= i) Lg[tri_at(i, k)] = A[ch_tri(a, b)];
     }
-    __syncthreads();
-  }
-  for (int e = t; e < ntri; e += 256) Lg[e] = Lp[e];
 }
 
 // Q = Y L^-T, 64 rows of Y per workgroup: row y solves L q^T = y^T by forward substitution.  Four lanes share a row (the
@@ -320,7 +345,7 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
       const size_t lds_t = lds_l + sizeof(double) * 64 * (size_t)(rb | 1);
       if ((e = gemm_f64_splitk(false, false, Yb, ld, Yb, ld, h->gpart, rb, rb, n, CHOLQR_KCHUNK, nsp, st))) return e;
       hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((long)rb * rb, 256)), dim3(256), 0, st, h->gpart, nsp, rb, h->U);
-      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), lds_l, st, h->U, rb, h->Cm, weak);
+      hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), 0, st, h->U, rb, h->Cm, weak);
       hipLaunchKernelGGL(trsm_rows_kernel, dim3(cdiv(n, 64)), dim3(256), lds_t, st, Yb, ld, n, rb, h->Cm, dstb, ld);
       return MUSED_OK;
     };
@@ -461,9 +486,7 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [] {
       const int tri = (int)(sizeof(double) * CHOLQR_MAX_R * (CHOLQR_MAX_R + 1) / 2);
-      attr_rc = hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tri);
-      if (attr_rc == hipSuccess)
-        attr_rc = hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      attr_rc = hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       tri + (int)(sizeof(double) * 64 * (CHOLQR_MAX_R | 1)));
     });
     MUSED_CHECK_HIP(attr_rc);
