@@ -27,6 +27,7 @@ struct Rsvd {
   int *deg, *rowptr, *colidx, *degT, *rowptrT, *colidxT, *stats, *pivstep, *flags;
   double *Q0, *Qa, *Qb, *Qf, *Bt, *prow, *tau, *wpart, *gpart, *evals, *U, *Cm, *Vsel, *embed, *sigma, *signs;
   EigPlan* eig;
+  EigPlan* eig_top;  // order 256, direct solver (trd.hip): used when 128 < r <= 256 and at most 128 components are asked for
   hipStream_t cap_stream;
   hipGraph_t graph;
   hipGraphExec_t exec;
@@ -404,10 +405,16 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
 
   const int nsplit = cdiv(n, GRAM_KCHUNK);
   RC(gemm_f64_splitk(false, false, h->Bt, ld, h->Bt, ld, h->gpart, rc, rc, n, GRAM_KCHUNK, nsplit, st));
-  const int en = h->eig_n;
+  // The r x r Gram of B: only its n_comp largest eigenpairs are used.  For 128 < r <= 256 and n_comp <= 128 (config 2 / 4:
+  // r = 138, n_comp = 128) the matrix is zero-padded to order 256 and goes to the direct solver of the FD rotation (top 128
+  // eigenpairs by tridiagonalisation; its certificate hands a rejected matrix to the Jacobi of the same plan): 0.7 ms
+  // instead of 1.3 ms for the persistent Jacobi at order 138.  MUSED_RSVD_EIG_TRD=0 turns it off.
+  const bool top = h->eig_top && n_comp <= 128 && rc > 128;
+  EigPlan* ep = top ? h->eig_top : h->eig;
+  const int en = top ? 256 : h->eig_n;
   hipLaunchKernelGGL(gram_reduce_pad_kernel, dim3(cdiv((long)en * en, 256)), dim3(256), 0, st, h->gpart, nsplit, rc,
-                     eig_plan_input(h->eig), en);
-  RC(eig_plan_run_inplace(h->eig, h->evals, h->U, st, false));
+                     eig_plan_input(ep), en);
+  RC(eig_plan_run_inplace(ep, h->evals, h->U, st, false));
   hipLaunchKernelGGL(rsvd_decide_kernel, dim3(1), dim3(1024), 0, st, h->evals, h->U, en, rc, n_comp, h->Cm, h->sigma);
   RC(gemm_f64(true, false, h->Bt, ld, 0, h->Cm, n_comp, 0, h->Vsel, n_comp, 0, n, n_comp, rc, 1, 1.0, st));
   hipLaunchKernelGGL(col_sign_kernel, dim3(n_comp), dim3(256), 0, st, h->Vsel, n, n_comp, n_comp, h->signs);
@@ -474,12 +481,23 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
   ALLOC(h->prow, 8 * (size_t)h->prow_len); ALLOC(h->tau, 8 * (size_t)r_max);
   ALLOC(h->wpart, 8 * ((size_t)r_max * cdiv(n_max, 512) + 2 * (size_t)n_max));
   ALLOC(h->gpart, 8 * (size_t)nsplit * r_max * r_max);
-  ALLOC(h->evals, 8 * (size_t)h->eig_n); ALLOC(h->U, 8 * (size_t)h->eig_n * h->eig_n);
+  const size_t en_max = (r_max > 128 && r_max <= 256) ? 256 : (size_t)h->eig_n;
+  ALLOC(h->evals, 8 * en_max); ALLOC(h->U, 8 * en_max * en_max);
   ALLOC(h->Cm, 8 * (size_t)r_max * r_max); ALLOC(h->sigma, 8 * (size_t)r_max); ALLOC(h->signs, 8 * (size_t)r_max);
 #undef ALLOC
   // flags[3]: the r x r eigensolve gave up (work-queue timeout, eig.hip) -> the result of that call is invalid
   int rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig, nullptr, 0, h->flags + 3);
   if (rc) return rc;
+  {
+    const char* te = getenv("MUSED_RSVD_EIG_TRD");
+    if (r_max > 128 && r_max <= 256 && !(te && te[0] == '0')) {
+      if ((rc = eig_plan_create(256, 1, h->sweeps, false, &h->eig_top, nullptr, EIG_PLAN_TOP_HALF, h->flags + 3))) return rc;
+      if (!eig_plan_direct_solver(h->eig_top)) {  // (MUSED_EIG_TRD=0): nothing gained by padding
+        eig_plan_destroy(h->eig_top);
+        h->eig_top = nullptr;
+      }
+    }
+  }
   if ((rc = gemm_f64_prepare_all())) return rc;
   {
     static std::once_flag once;
@@ -503,6 +521,7 @@ int mused_rsvd_destroy(void* handle) {
   rsvd_drop_graph(h);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   eig_plan_destroy(h->eig);
+  if (h->eig_top) eig_plan_destroy(h->eig_top);
   void* bufs[] = {h->mask, h->mask_t, h->deg, h->degT, h->rowptr, h->rowptrT, h->colidx, h->colidxT, h->stats,
                   h->flags, h->pivstep, h->Q0, h->Qa, h->Qb, h->Qf, h->Bt, h->Vsel, h->embed, h->prow, h->tau,
                   h->wpart, h->gpart, h->evals, h->U, h->Cm, h->sigma, h->signs};
