@@ -218,9 +218,10 @@ def cpu_baseline(cfg, kind, seed, with_swfd=True):
         "cores": threads,
         "kind": "port",
         "sample": f"1 window of {W} rows through oracle adjacency+fuse ({t1 - t0:.2f}s), eigenstep ({t2 - t1:.2f}s), "
-                  f"k-means ({t3 - t2:.2f}s); SWFD oracle timed on {swfd_rows} rows "
-                  f"({t_swfd_per_row * 1e3:.2f} ms/row) and extrapolated to the window; BLAS/OpenMP pools capped at "
-                  f"{threads} threads",
+                  f"k-means ({t3 - t2:.2f}s); "
+                  + (f"SWFD oracle timed on {swfd_rows} rows ({t_swfd_per_row * 1e3:.2f} ms/row) and extrapolated to the window; "
+                     if with_swfd else "no sketch stage (--no-swfd); ")
+                  + f"BLAS/OpenMP pools capped at {threads} threads",
         "window_seconds": window_s,
         "value_without_swfd": W / (t3 - t0),
     }
