@@ -50,7 +50,7 @@ struct GemmArgs {
 // row (t & 127) and the 8 consecutive k's of half (t >> 7).
 template <typename TIn, bool VEC>
 __device__ __forceinline__ void stage_load_kc(const TIn* __restrict__ src, long ld, int r0, int nrows, int k0,
-                                              int kend, double (&r)[8]) {
+                                              int kend, TIn (&r)[8]) {
   const int m = threadIdx.x & 127;
   const int kh = threadIdx.x >> 7;
   const int row = r0 + m;
@@ -74,26 +74,30 @@ __device__ __forceinline__ void stage_load_kc(const TIn* __restrict__ src, long 
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = (k + j < kend) ? (double)p[j] : 0.0;
+      for (int j = 0; j < 8; ++j) r[j] = (k + j < kend) ? p[j] : (TIn)0;
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = 0.0;
+    for (int j = 0; j < 8; ++j) r[j] = (TIn)0;
   }
 }
 
-__device__ __forceinline__ void stage_store_kc(double* __restrict__ lds, const double (&r)[8]) {
+// (The staging registers hold the operand in its INPUT type and are converted to fp64 here, on the way into LDS: a conversion
+// at load time makes every load wait for its data at once -- the fp32 similarity GEMM then exposed two global-load
+// latencies per K step.)
+template <typename TIn>
+__device__ __forceinline__ void stage_store_kc(double* __restrict__ lds, const TIn (&r)[8]) {
   const int m = threadIdx.x & 127;
   const int kh = threadIdx.x >> 7;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) lds[(kh * 8 + j) * GEMM_LD + m] = r[j];
+  for (int j = 0; j < 8; ++j) lds[(kh * 8 + j) * GEMM_LD + m] = (double)r[j];
 }
 
 // MN-contiguous operand stored [K][MN]: thread t owns k-row (t >> 4) and the 8
 // consecutive columns starting at (t & 15) * 8.
 template <typename TIn, bool VEC>
 __device__ __forceinline__ void stage_load_mc(const TIn* __restrict__ src, long ld, int c0, int ncols, int k0,
-                                              int kend, double (&r)[8]) {
+                                              int kend, TIn (&r)[8]) {
   const int kk = threadIdx.x >> 4;
   const int c = c0 + (threadIdx.x & 15) * 8;
   const int k = k0 + kk;
@@ -116,20 +120,50 @@ __device__ __forceinline__ void stage_load_mc(const TIn* __restrict__ src, long 
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = (c + j < ncols) ? (double)p[j] : 0.0;
+      for (int j = 0; j < 8; ++j) r[j] = (c + j < ncols) ? p[j] : (TIn)0;
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = 0.0;
+    for (int j = 0; j < 8; ++j) r[j] = (TIn)0;
   }
 }
 
-__device__ __forceinline__ void stage_store_mc(double* __restrict__ lds, const double (&r)[8]) {
+template <typename TIn>
+__device__ __forceinline__ void stage_store_mc(double* __restrict__ lds, const TIn (&r)[8]) {
   const int kk = threadIdx.x >> 4;
   const int c = (threadIdx.x & 15) * 8;
   double* p = lds + kk * GEMM_LD + c;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = r[j];
+  for (int j = 0; j < 8; ++j) p[j] = (double)r[j];
+}
+
+// Full-tile variants (all 128 rows / columns and all 16 k's inside the operand, vectorisable): no per-thread branch, so the
+// loads stay in flight across the MFMAs of the current K step (with the bounds checks of the general variants the compiler
+// waits for the data at the end of each conditional region).
+template <typename TIn>
+__device__ __forceinline__ void stage_load8(const TIn* __restrict__ p, TIn (&r)[8]) {
+  if (sizeof(TIn) == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  } else {
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double2 v = q[j];
+      r[2 * j] = v.x;
+      r[2 * j + 1] = v.y;
+    }
+  }
+}
+template <typename TIn>
+__device__ __forceinline__ void stage_load_kc_full(const TIn* __restrict__ src, long ld, int r0, int k0, TIn (&r)[8]) {
+  stage_load8(src + (long)(r0 + (threadIdx.x & 127)) * ld + k0 + (threadIdx.x >> 7) * 8, r);
+}
+template <typename TIn>
+__device__ __forceinline__ void stage_load_mc_full(const TIn* __restrict__ src, long ld, int c0, int k0, TIn (&r)[8]) {
+  stage_load8(src + (long)(k0 + (threadIdx.x >> 4)) * ld + c0 + (threadIdx.x & 15) * 8, r);
 }
 
 // XCD-aware workgroup id: blocks b and b+8 share an XCD (observed round-robin
@@ -159,11 +193,18 @@ __device__ __forceinline__ void gemm_tile_mainloop(const GemmArgs& g, const TA* 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-  double ra[8], rb[8];
+  TA ra[8];
+  TB rb[8];
   const int nkt = (k_hi - k_lo + GEMM_BK - 1) / GEMM_BK;
 
+  const bool full_mn = VEC && m0 + GEMM_BM <= g.M && n0 + GEMM_BN <= g.N;  // (uniform over the workgroup)
   auto load_tile = [&](int kt) {
     const int k0 = k_lo + kt * GEMM_BK;
+    if (full_mn && k0 + GEMM_BK <= k_hi) {
+      if (A_KC) stage_load_kc_full<TA>(A, g.lda, m0, k0, ra); else stage_load_mc_full<TA>(A, g.lda, m0, k0, ra);
+      if (B_KC) stage_load_kc_full<TB>(B, g.ldb, n0, k0, rb); else stage_load_mc_full<TB>(B, g.ldb, n0, k0, rb);
+      return;
+    }
     if (A_KC) stage_load_kc<TA, VEC>(A, g.lda, m0, g.M, k0, k_hi, ra);
     else      stage_load_mc<TA, VEC>(A, g.lda, m0, g.M, k0, k_hi, ra);
     if (B_KC) stage_load_kc<TB, VEC>(B, g.ldb, n0, g.N, k0, k_hi, rb);

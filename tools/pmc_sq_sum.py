@@ -7,6 +7,7 @@ for r in csv.DictReader(open(f)):
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     cnt[(k, r["Counter_Name"])] += 1
 for k, v in acc.items():
-    if "osjw" in k or "osjq" in k:
+    flt = sys.argv[2] if len(sys.argv) > 2 else "osj"
+    if flt in k:
         n = max(cnt[(k, c)] for c in v)
         print(k, "launches", n, json.dumps({c: round(x / n, 1) for c, x in v.items()}))
