@@ -248,7 +248,7 @@ def max_row_sq_norm(fused) -> float:
 # --------------------------------------------------------------------------
 
 
-def randomized_svd_reduce(matrix, reduced_dim, seed, n_iter=5, n_oversamples=10):
+def randomized_svd_reduce(matrix, reduced_dim, seed, n_iter=5, n_oversamples=10, info=None):
     """matrix_operations.py:143-147 = TruncatedSVD(n_components=min(reduced_dim,
     n_cols-1), random_state=seed).fit_transform(matrix), restated from
     sklearn:decomposition/_truncated_svd.py:225-274 and
@@ -273,6 +273,8 @@ def randomized_svd_reduce(matrix, reduced_dim, seed, n_iter=5, n_oversamples=10)
     Q, _ = scipy.linalg.qr(M @ Q, mode="economic", check_finite=False)
     B = Q.T @ M
     Uhat, s, Vt = scipy.linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
+    if info is not None:  # test tooling: all n_comp + n_oversamples singular values of B (is the cut inside a multiple one?)
+        info["sigma_all"] = np.array(s)
     U = Q @ Uhat
     if transpose:
         U, s, Vt = Vt[:n_comp, :].T, s[:n_comp], U[:, :n_comp].T
@@ -388,11 +390,14 @@ def process_streaming_data(
                 if reduced.shape[0] != window_size:  # main.py:73-76
                     reduced = reduced.T
             else:
-                reduced, sig, _ = randomized_svd_reduce(fused, reduced_dim, seed)
+                rinfo = {} if trace is not None else None
+                reduced, sig, _ = randomized_svd_reduce(fused, reduced_dim, seed, info=rinfo)
             clusters = perform_clustering(reduced, n_clusters, seed)
             if trace is not None:  # (recorded before the matching, which may raise: main.py:331 lets that propagate)
                 trace.append(dict(trigger=i, sigma=np.asarray(sig), raw=np.asarray(clusters), n_clusters=n_clusters,
                                   reduced=np.asarray(reduced)))
+                if approach != "SWFDMC":
+                    trace[-1]["sigma_all"] = rinfo.get("sigma_all")
             matched = match_clusters(prev, clusters, method="hungarian", min_overlap=3)
             if matched is None or len(matched) == 0:  # main.py:114-116
                 matched = np.full(window_size, 0)
