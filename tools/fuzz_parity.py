@@ -285,7 +285,7 @@ def rsvd_case(rng, i):
             "oracle's labels are stable under a 1e-15 perturbation of its embedding and a 1e-13 perturbation of its matrix")
     lab_dev = mo.perform_clustering_on_device(torch.from_numpy(emb_d).cuda(), nc, seed)
     assert np.array_equal(lab_dev, lab_d), f"rsvd case {i}: device k-means differs from scikit-learn on the same embedding"
-    return f"rsvd n={n:3d} k={k:2d} M={M} l={ell:2d} seed={seed:3d} clear={int(clear.sum())}/{ell} labels {'equal' if same else 'differ in ' + str(int((lab_o != lab_d).sum())) + ' rows: oracle k-means ill-posed (flips under a 1e-15 perturbation)'}"
+    return f"rsvd n={n:3d} k={k:2d} M={M} l={ell:2d} seed={seed:3d} clear={int(clear.sum())}/{ell} labels {'equal' if same else 'differ in ' + str(int((lab_o != lab_d).sum())) + ' rows: ill-posed on the reference side (oracle labels move under a 1e-15 perturbation of its embedding or a 1e-13 perturbation of its matrix)'}"
 
 
 def pipeline_case(rng, i):
