@@ -191,7 +191,33 @@ __global__ __launch_bounds__(256) void trsm_rows_kernel(const double* __restrict
   __syncthreads();
   const int rr = t >> 2, part = t & 3;  // the 4 lanes of a quad work on row rr
   double* q = rows + rr * rs;
-  for (int k = 0; k < r; ++k) {
+  // Four columns per pass: the sums over the columns already solved share one read of q[m] for four FMAs (5 LDS reads per 4
+  // FMAs instead of 8), then the 4 x 4 triangle of the block is finished by every lane of the quad for itself.
+  int k = 0;
+  for (; k + 4 <= r; k += 4) {
+    const double* l0 = Lp + tri_at(k, 0);
+    const double* l1 = Lp + tri_at(k + 1, 0);
+    const double* l2 = Lp + tri_at(k + 2, 0);
+    const double* l3 = Lp + tri_at(k + 3, 0);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+    for (int m = part; m < k; m += 4) {
+      const double qm = q[m];
+      s0 = fma(l0[m], qm, s0);
+      s1 = fma(l1[m], qm, s1);
+      s2 = fma(l2[m], qm, s2);
+      s3 = fma(l3[m], qm, s3);
+    }
+    s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1); s3 += __shfl_xor(s3, 1);
+    s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2); s3 += __shfl_xor(s3, 2);
+    const double q0 = (q[k] - s0) / l0[k];
+    const double q1 = (q[k + 1] - fma(l1[k], q0, s1)) / l1[k + 1];
+    const double q2 = (q[k + 2] - fma(l2[k + 1], q1, fma(l2[k], q0, s2))) / l2[k + 2];
+    const double q3 = (q[k + 3] - fma(l3[k + 2], q2, fma(l3[k + 1], q1, fma(l3[k], q0, s3)))) / l3[k + 3];
+    if (part == 0) { q[k] = q0; q[k + 1] = q1; q[k + 2] = q2; q[k + 3] = q3; }
+    // the quad reads these entries in later passes: same wave, LDS operations of a wave complete in order
+  }
+  for (; k < r; ++k) {
     const double* lrow = Lp + tri_at(k, 0);
     double sum = 0.0, sum1 = 0.0, sum2 = 0.0, sum3 = 0.0;
     int m = part;
