@@ -111,9 +111,11 @@ __device__ __forceinline__ void chol_block_columns(double (&A)[CH_NB * (CH_NB + 
     double lr[CH_NB], lc[CH_NB];
 #pragma unroll
     for (int a = B; a < CH_NB; ++a) {
-      const int i = p + 16 * a, k = q + 16 * a;
-      lr[a] = (i > j && i < r) ? cb[i] * inv : 0.0;
-      lc[a] = (k > j && k < r) ? cb[k] * inv : 0.0;
+      // rows / columns beyond j: every one of a later block, those of block B past jj; entries at and beyond r are zeros
+      // (never written since the vectors were cleared): no bounds test per entry
+      const double xr = cb[p + 16 * a] * inv, xc = cb[q + 16 * a] * inv;
+      lr[a] = (a > B || p > jj) ? xr : 0.0;
+      lc[a] = (a > B || q > jj) ? xc : 0.0;
     }
 #pragma unroll
     for (int b = B; b < CH_NB; ++b)
@@ -154,6 +156,8 @@ __global__ __launch_bounds__(256) void chol_kernel(const double* __restrict__ G,
   __syncthreads();
   const double delta = s_delta;
   const double weak = 1e-11 * (delta / (16.0 * r * 2.220446049250313e-16));
+  for (int i = t; i < 2 * 16 * CH_NB; i += 256) (&colbuf[0][0])[i] = 0.0;  // (entries >= r are read as zeros, see chol_block_columns)
+  __syncthreads();
   chol_block_columns<0>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
   chol_block_columns<1>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
   chol_block_columns<2>(A, colbuf, r, t, p, q, delta, weak, weak_flag);
