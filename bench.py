@@ -20,8 +20,9 @@ says how many slots): that time is part of `value`.  `single_lane` is what ONE s
 (no batching across windows): rows/s and p50 window latency.
 
     python bench.py                       # 1 GPU, K = 20, W = 5 (what the driver runs)
+    python bench.py --gpus N              # starts N ranks itself (a child `python -m torch.distributed.run`, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W     # the driver's form: used as launched
 
 Multi-GPU: every rank owns a contiguous block of windows of the stream (mused_amd/distributed.py):
 weak scaling, no data-path collective; one all-gather of raw labels at the end.
@@ -31,6 +32,8 @@ import glob
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -58,6 +61,10 @@ WORKLOADS = {
                name="synthetic two modalities d=512+512 l=128 window=10000 k=50 (BASELINE config 4)"),
     # small plumbing case (configs[0] shapes) for quick checks
     "c1": dict(W=500, dims=(64,), ell=16, k=50, lanes=4, name="synthetic d=64 l=16 window=500 k=50 (BASELINE config 1)"),
+    # the reference's OWN default parameters (/root/reference/main.py:305-313: window_size 2000, reduced_dim 50, k_basis 50) on a
+    # 256-d synthetic stream: rotations of order 100, queries of order 150, eigenstep at r = 60 -- all on the direct solver
+    "refdef": dict(W=2000, dims=(256,), ell=50, k=50, lanes=10,
+                   name="synthetic d=256 l=50 window=2000 k=50 (the reference's default parameters, main.py:305-313)"),
     # the reference's OWN use of the sketch (main.py:58-76, approach SWFDMC): SeqBasedSWFD over the rows of the fused W x W
     # adjacency (d = W = 10,000, bit rows), R from the first window, sketch transposed to (W, l) -> k-means -> matching.
     # One sketch object for the whole stream: windows are consumed strictly in order (no lanes).
@@ -80,6 +87,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-swfd", action="store_true", help="diagnostic: skip the feature-row SWFD stage")
     ap.add_argument("--no-single-lane", action="store_true", help="skip the in-order single-lane measurement")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse the N-rank launch only: every rank joins the process group (gloo, CPU), one all-reduce, "
+                         "rank 0 prints the world size -- no GPU is touched")
     ap.add_argument("--lanes", type=int, default=0,
                     help="contiguous blocks of the rank's windows whose sketches advance in lockstep inside the same "
                          "launches (0 = the workload's default; 1 = strictly one window at a time)")
@@ -236,9 +246,7 @@ def run_swfdmc(args, cfg):
     from mused_amd.pipeline import StreamPipeline
     from mused_amd.swfd import SeqBasedSWFD
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = rank_env(args)
     backend = os.environ.get("MUSED_DIST_BACKEND", "nccl")
     if "MUSED_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["MUSED_FORCE_DEVICE"])
@@ -289,7 +297,8 @@ def run_swfdmc(args, cfg):
         if direct and n_launch:
             us = 1e3 * t_ms / n_launch
             tfl = (solved / n_launch) * fl / (us * 1e-6) / 1e12
-            roof = {"kernel": "trd_a .. trd_d kernels (direct eigensolver of the FD rotation, order 256; see the c2 line)", "bound": "valu",
+            roof = {"kernel": "trd_a .. trd_d kernels (direct eigensolver of the FD rotation, order 256; see the c2 line)", "bound": "mfma",
+                    "bound_detail": "fp64 vector ALU + fp64 MFMA back-transformation, priced against the 78.6 TFLOP/s both share",
                     "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP64_PEAK_TFLOPS, "traffic": None,
                     "launch_us": us, "launches_timed": n_launch, "matrices_solved_per_launch_avg": solved / n_launch}
         out = np.asarray(pipe.out[n_warm * W:], dtype=np.int64)
@@ -301,6 +310,8 @@ def run_swfdmc(args, cfg):
             "config": {"workload": cfg["name"], "stream": args.kind, "W": W, "d_features": d, "d_sketch": W, "l": ell, "k": k,
                        "swfd_levels": pipe.swfd.L, "R": R,
                        "parallelism": f"{world} in-order stream block(s), one per GPU; the halo window is the last warm-up window",
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "collective_backend": (dist.get_backend() if world > 1 else None),
                        "labels_sha16": hashlib.sha256(out.tobytes()).hexdigest()[:16]},
             "p50_window_latency_ms": float(np.median(lat) * 1e3) if len(lat) else None,
             "roofline": roof,
@@ -313,6 +324,48 @@ def run_swfdmc(args, cfg):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process (never exec: this process may
+    not be replaced once anything has touched the GPU, and the child's exit code is ours) -- `python -m
+    torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1 -- before torch is imported here.  Rank 0 of the
+    child prints the JSON line on the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks' processes here
+    # (the launcher would pin every rank to ONE OpenMP thread: the host side -- k-means++ seeding, Hungarian chain -- gets its share of the cores)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_env(args):
+    """(rank, local_rank, world) of this process; a launcher's WORLD_SIZE must agree with --gpus."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    return rank, local_rank, world
+
+
+def launch_check(args):
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = rank_env(args)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_counted": int(t.item()), "backend": "gloo"}))
+    dist.destroy_process_group()
+
+
 def newest_profile(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
@@ -320,6 +373,10 @@ def newest_profile(pattern):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.launch_check:
+        return launch_check(args)
     cfg = dict(WORKLOADS[args.workload])
     if args.workload == "swfdmc":
         return run_swfdmc(args, cfg)
@@ -329,9 +386,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = rank_env(args)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -630,7 +685,9 @@ def main():
                               f"workgroup = one CU per Gram matrix of order {n}, matrix in registers, fp64 vector ALU), "
                               f"{np.mean([sk.lanes * 2 * sk.L for sk in sketches]):.0f} matrices per launch of which {per_launch:.1f} "
                               f"are solved (duplicates / frozen sketches skipped), {ns} independent launch streams",
-                    "bound": "valu",
+                    "bound": "mfma",
+                    "bound_detail": "fp64 vector ALU (no MFMA in this kernel); priced against the fp64 rate of the chip, 78.6 TFLOP/s, "
+                                    "which on gfx950 is the fp64 MFMA peak as well",
                     "achieved": tfl_a,
                     "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s",
@@ -649,7 +706,7 @@ def main():
                         "launch_us": launch_us, "flop_per_matrix": flop_solve, "achieved": tfl, "frac": tfl / FP64_PEAK_TFLOPS,
                         "per_cu_frac": fl / (launch_us * 1e-6) / 1e9 / cu_peak, "traffic": tr,
                     },
-                    "note": "`bound`: the contract's enum is hbm | mfma; this kernel is neither -- fp64 VALU work in a chain of "
+                    "note": "`bound`: the contract's enum is hbm | mfma; this kernel is compute, not bytes -- fp64 VALU work in a chain of "
                             "dependent, barrier-separated steps (one CU per matrix), priced on 4 n^3 / 3 flops per matrix against "
                             "the fp64 vector rate of the chip (78.6 TFLOP/s, the same number as the fp64 MFMA peak).  "
                             "A launch occupies `matrices_solved_per_launch_avg` of the 256 CUs: `per_cu` is what one busy CU "
@@ -794,7 +851,8 @@ def main():
         except Exception:
             golden_ok = None
         res = {
-            "metric": "stream rows/sec, d=1024 l=128 window=10k synthetic (SWFD + kNN similarity + eigenstep + labels)",
+            "metric": ("stream rows/sec, d=1024 l=128 window=10k synthetic (SWFD + kNN similarity + eigenstep + labels)"
+                       if args.workload in ("c2", "c4") else f"stream rows/sec, {cfg['name']} (SWFD + kNN similarity + eigenstep + labels)"),
             "value": value,
             "unit": "rows/s",
             "n_gpus": world,
@@ -812,6 +870,8 @@ def main():
                 "W": W, "d": D, "l": ell, "k": k, "modalities": M,
                 "swfd_levels": L_sk,
                 "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {B} lock-step lane(s) per GPU",
+                "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                "collective_backend": (dist.get_backend() if world > 1 else None),
                 "lanes_per_gpu": B,
                 "padded_window_slots": padded_slots,
                 "labels_sha16": sha16,

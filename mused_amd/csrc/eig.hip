@@ -42,8 +42,10 @@ struct EigPlan {
   unsigned* q;        // unit ring: 0 = empty, else 1 + ((matrix * 256 + global round) * 4 + block pair)
   unsigned qcap;
   struct OsjqCtl* qctl;
-  // direct solver for order 256 / top half (trd.hip): runs first, the queue Jacobi then takes the matrices it rejected
+  // direct solver for orders <= 256 / the leading pairs only (trd.hip): runs first, the queue Jacobi then takes the matrices it rejected
   int trd;
+  int trd_need;        // leading eigenpairs the caller reads
+  int trd_cert_all;    // every one of them must pass the certificate (eigenstep) / those that survive the FD shrink
   double* trd_ws;
   int* trd_done;       // per matrix: 1 = solved by the direct solver (the Jacobi skips it)
   unsigned long long q_timeout;  // ticks of s_memrealtime (100 MHz) a consumer waits for its ticket (3 s; MUSED_EIG_QUEUE_TIMEOUT_TICKS)
@@ -1080,7 +1082,8 @@ static int osj_padded_order(int n) {
   return ((n + 127) / 128) * 128;
 }
 
-int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep, int flags, int* err_out) {
+int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep, int flags, int* err_out,
+                    int need) {
   MUSED_REQUIRE(n >= 2 && n % 2 == 0 && n <= 1024 && batch >= 1 && sweeps >= 1,
                 "eig_plan_create: the order must be even and <= 1024 (n=%d)", n);
   CaptureLock resource_guard(capture_mutex());  // allocations + capture: not beside another thread's capture
@@ -1122,9 +1125,12 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
       const bool fits = p->wavek && p->ldn <= 256 && nbq >= 2 && sweeps * (nbq - 1) <= 255 && batch <= (1 << 21);
       bool want = qe ? (qe[0] == '1') : ((long)batch * (nbq / 2) <= 224);
       {
-        // direct solver (MUSED_EIG_TRD=0 turns it off): order 256 exactly, callers that read the top half only
+        // direct solver (MUSED_EIG_TRD=0 turns it off): orders up to 256, callers that read the leading pairs only -- the
+        // top half (FD rotation: those that survive the shrink are certified) or the `need` largest, all certified (eigenstep)
         const char* te = getenv("MUSED_EIG_TRD");
-        p->trd = ((flags & EIG_PLAN_TOP_HALF) && n == 256 && p->ldn == 256 && fits && !(te && te[0] == '0')) ? 1 : 0;
+        p->trd_need = (flags & (EIG_PLAN_TOP_NEED | EIG_PLAN_TOP_FD)) ? need : ((flags & EIG_PLAN_TOP_HALF) ? n / 2 : 0);
+        p->trd_cert_all = (flags & EIG_PLAN_TOP_NEED) ? 1 : 0;
+        p->trd = (p->trd_need > 0 && trd_supports(n, p->ldn, p->trd_need) && fits && !(te && te[0] == '0')) ? 1 : 0;
         if (p->trd) want = true;  // its rare rejects go through the one-launch queue solver (nothing queued: it exits at once)
       }
       p->use_queue = (fits && want) ? 1 : 0;
@@ -1322,9 +1328,8 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->trd) {
-      if (!p->direct) { set_error("eig_plan_run_inplace: the direct solver needs the caller to fill eig_plan_input"); return MUSED_ERR_STATE; }
-      const int rc = trd_solve(p->Gc, p->batch, p->rep, p->trd_done, p->trd_ws, st, nullptr, rec ? p->work : nullptr,
-                               (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr);
+      const int rc = trd_solve(p->Gc, p->n, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done, p->trd_ws,
+                               st, nullptr, rec ? p->work : nullptr, (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr);
       if (rc) return rc;
       if (rec) {  // the events of a direct-solver plan bracket the direct solver alone (the Jacobi behind it only sees rejects)
         MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));

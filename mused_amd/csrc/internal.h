@@ -62,10 +62,12 @@ struct EigPlan;
 // captures a larger pipeline that contains this solve).
 constexpr int EIG_PLAN_FIXED_SWEEPS = 1;  // always `sweeps` sweeps (no convergence flags)
 constexpr int EIG_PLAN_NO_SORT = 2;       // no column sorting: column j of the result descends from column j of the input
-constexpr int EIG_PLAN_TOP_HALF = 4;      // the caller reads only the n / 2 largest eigenpairs (FD rotation): order 256 goes to the
-                                          // direct solver (trd.hip), the Jacobi takes what its certificate rejects
+constexpr int EIG_PLAN_TOP_HALF = 4;      // the caller reads only the n / 2 largest eigenpairs (FD rotation): orders the direct
+                                          // solver covers (trd.hip) go to it, the Jacobi takes what its certificate rejects
+constexpr int EIG_PLAN_TOP_NEED = 8;      // the caller reads the `need` largest eigenpairs, ALL of which must be certified (eigenstep)
+constexpr int EIG_PLAN_TOP_FD = 16;       // as TOP_HALF with an explicit `need` (sketch query: the l largest of 3 l or 4 l)
 int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out, const int* rep = nullptr, int flags = 0,
-                    int* err_out = nullptr);
+                    int* err_out = nullptr, int need = 0);
 // rep (device, batch ints, optional, read at every solve): matrix b is solved only when rep[b] == b
 // err_out (device int, optional): OR-ed with 1 by a solve of the persistent work-queue solver that gave up waiting
 // (timeout: the matrices are left partially rotated and the results of that solve are invalid)
@@ -86,10 +88,12 @@ double* eig_plan_input(EigPlan* p);  // (batch x n x n) device buffer the caller
 bool eig_plan_columns(EigPlan* p, const double** cols, const double** lam, int* ld);
 int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t stream, bool allow_graph);
 
-// trd.hip: direct solver for order 256, top 128 eigenpairs (tridiagonalisation + multisection + twisted factorisation)
+// trd.hip: direct solver for orders <= 256, the `need` <= 128 largest eigenpairs (tridiagonalisation + multisection +
+// twisted factorisation + back-transformation); matrices column-major with leading dimension ldn (n <= ldn <= 256)
 size_t trd_workspace_doubles(int batch);
 int trd_prepare();
-int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, long long* dbg_clk = nullptr,
-              unsigned long long* work = nullptr, hipEvent_t after_a = nullptr);
+bool trd_supports(int n, int ldn, int need);
+int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
+              hipStream_t st, long long* dbg_clk = nullptr, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr);
 
 }  // namespace mused

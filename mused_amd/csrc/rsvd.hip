@@ -22,12 +22,14 @@ namespace mused {
 struct Rsvd {
   int n_max, r_max, eig_n, sweeps;
   long prow_len;  // doubles behind prow (LU workspace)
+  long cm_len;    // doubles behind Cm
   long nnz_cap;
   unsigned long long *mask, *mask_t;
   int *deg, *rowptr, *colidx, *degT, *rowptrT, *colidxT, *stats, *pivstep, *flags;
   double *Q0, *Qa, *Qb, *Qf, *Bt, *prow, *tau, *wpart, *gpart, *evals, *U, *Cm, *Vsel, *embed, *sigma, *signs;
   EigPlan* eig;
-  EigPlan* eig_top;  // order 256, direct solver (trd.hip): used when 128 < r <= 256 and at most 128 components are asked for
+  EigPlan* eig_top;  // same order on the direct solver (trd.hip; r <= 256): used when at most top_need components are asked for
+  int top_need;
   hipStream_t cap_stream;
   hipGraph_t graph;
   hipGraphExec_t exec;
@@ -79,6 +81,8 @@ __device__ __forceinline__ int tri_at(int i, int k) { return i * (i + 1) / 2 + k
 // applies the rank-1 update to its elements; the vector is double-buffered, so the next column's owners never wait.
 // (The first version worked on a packed triangle in LDS with a rank-8 trailing update per panel: 220 us for r = 138,
 // bound by LDS round trips; this one: see DESIGN section 4e.)
+constexpr long CHOLQR_P_OFF = 16384;  // offset (doubles) of the two-block path's projection scratch inside Cm
+static_assert(CHOLQR_P_OFF >= (long)CHOLQR_MAX_R * (CHOLQR_MAX_R + 1) / 2, "the packed triangle must end before the projection scratch");
 constexpr int CH_NB = 9;  // 16 x 9 = 144 >= CHOLQR_MAX_R
 static_assert(16 * CH_NB >= CHOLQR_MAX_R, "chol_kernel holds at most 16 * CH_NB rows");
 __host__ __device__ constexpr int ch_tri(int a, int b) { return a * (a + 1) / 2 + b; }
@@ -384,7 +388,9 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
     const int r1 = r / 2, r2 = r - r1;
     int e;
     if ((e = cholqr_block(Y, r1, dst))) return e;                                   // Q1 -> dst[:, :r1]
-    double* P = h->Cm + 16384;                                                      // r1 x r2 (behind the packed L)
+    // r1 x r2, behind the packed L of either block (<= CHOLQR_MAX_R (CHOLQR_MAX_R + 1) / 2 = 10,296 doubles)
+    MUSED_REQUIRE(CHOLQR_P_OFF + (long)r1 * r2 <= h->cm_len, "rsvd: projection scratch of the two-block Cholesky-QR does not fit (r = %d)", r);
+    double* P = h->Cm + CHOLQR_P_OFF;
     if ((e = gemm_f64_splitk(false, false, dst, ld, Y + r1, ld, h->gpart, r1, r2, n, CHOLQR_KCHUNK, nsp, st))) return e;
     if ((e = gemm_splitk_reduce(h->gpart, nsp, (long)r1 * r2, P, st))) return e;   // P = Q1^T Y2
     if ((e = gemm_f64(true, false, dst, ld, 0, P, r2, 0, h->Vsel, r2, 0, n, r2, r1, 1, 1.0, st))) return e;  // Q1 P
@@ -435,13 +441,13 @@ static int rsvd_enqueue(Rsvd* h, int n, int r, int n_comp, int n_iter, hipStream
 
   const int nsplit = cdiv(n, GRAM_KCHUNK);
   RC(gemm_f64_splitk(false, false, h->Bt, ld, h->Bt, ld, h->gpart, rc, rc, n, GRAM_KCHUNK, nsplit, st));
-  // The r x r Gram of B: only its n_comp largest eigenpairs are used.  For 128 < r <= 256 and n_comp <= 128 (config 2 / 4:
-  // r = 138, n_comp = 128) the matrix is zero-padded to order 256 and goes to the direct solver of the FD rotation (top 128
-  // eigenpairs by tridiagonalisation; its certificate hands a rejected matrix to the Jacobi of the same plan): 0.7 ms
-  // instead of 1.3 ms for the persistent Jacobi at order 138.  MUSED_RSVD_EIG_TRD=0 turns it off.
-  const bool top = h->eig_top && n_comp <= 128 && rc > 128;
+  // The r x r Gram of B: only its n_comp largest eigenpairs are used.  For r <= 256 and n_comp <= 128 (config 2 / 4:
+  // r = 138, n_comp = 128; the reference's default: r = 60, n_comp = 50) it goes to the direct solver of the FD rotation
+  // (the leading pairs by tridiagonalisation, every one of them certified; a rejected matrix goes to the Jacobi of the
+  // same plan): 0.7 ms instead of 1.3 ms for the persistent Jacobi at order 138.  MUSED_RSVD_EIG_TRD=0 turns it off.
+  const bool top = h->eig_top && n_comp <= h->top_need;
   EigPlan* ep = top ? h->eig_top : h->eig;
-  const int en = top ? 256 : h->eig_n;
+  const int en = h->eig_n;
   hipLaunchKernelGGL(gram_reduce_pad_kernel, dim3(cdiv((long)en * en, 256)), dim3(256), 0, st, h->gpart, nsplit, rc,
                      eig_plan_input(ep), en);
   RC(eig_plan_run_inplace(ep, h->evals, h->U, st, false));
@@ -511,17 +517,26 @@ static int rsvd_create_impl(Rsvd* h, int n_max, int r_max, long nnz_cap, int swe
   ALLOC(h->prow, 8 * (size_t)h->prow_len); ALLOC(h->tau, 8 * (size_t)r_max);
   ALLOC(h->wpart, 8 * ((size_t)r_max * cdiv(n_max, 512) + 2 * (size_t)n_max));
   ALLOC(h->gpart, 8 * (size_t)nsplit * r_max * r_max);
-  const size_t en_max = (r_max > 128 && r_max <= 256) ? 256 : (size_t)h->eig_n;
+  const size_t en_max = (size_t)h->eig_n;
   ALLOC(h->evals, 8 * en_max); ALLOC(h->U, 8 * en_max * en_max);
-  ALLOC(h->Cm, 8 * (size_t)r_max * r_max); ALLOC(h->sigma, 8 * (size_t)r_max); ALLOC(h->signs, 8 * (size_t)r_max);
+  {
+    // Cm holds the packed Cholesky factor and, for CHOLQR_MAX_R < r <= 2 CHOLQR_MAX_R, the r1 x r2 projection of the
+    // two-block path behind it (round 3 sized it r_max^2 only: 16384 + r1 r2 > r^2 for r = 144 .. 147)
+    const long r1m = r_max / 2, r2m = r_max - r1m;
+    const long two_block = (r_max > CHOLQR_MAX_R && r_max <= 2 * CHOLQR_MAX_R) ? CHOLQR_P_OFF + r1m * r2m : 0;
+    h->cm_len = (long)r_max * r_max > two_block ? (long)r_max * r_max : two_block;
+  }
+  ALLOC(h->Cm, 8 * (size_t)h->cm_len); ALLOC(h->sigma, 8 * (size_t)r_max); ALLOC(h->signs, 8 * (size_t)r_max);
 #undef ALLOC
   // flags[3]: the r x r eigensolve gave up (work-queue timeout, eig.hip) -> the result of that call is invalid
   int rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig, nullptr, 0, h->flags + 3);
   if (rc) return rc;
   {
     const char* te = getenv("MUSED_RSVD_EIG_TRD");
-    if (r_max > 128 && r_max <= 256 && !(te && te[0] == '0')) {
-      if ((rc = eig_plan_create(256, 1, h->sweeps, false, &h->eig_top, nullptr, EIG_PLAN_TOP_HALF, h->flags + 3))) return rc;
+    if (h->eig_n <= 256 && !(te && te[0] == '0')) {
+      h->top_need = h->eig_n < 128 ? h->eig_n : 128;
+      if ((rc = eig_plan_create(h->eig_n, 1, h->sweeps, false, &h->eig_top, nullptr, EIG_PLAN_TOP_NEED, h->flags + 3, h->top_need)))
+        return rc;
       if (!eig_plan_direct_solver(h->eig_top)) {  // (MUSED_EIG_TRD=0): nothing gained by padding
         eig_plan_destroy(h->eig_top);
         h->eig_top = nullptr;

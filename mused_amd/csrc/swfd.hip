@@ -712,8 +712,12 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
   int rc;
   if ((rc = gemm_f64_prepare_all())) return rc;
   if ((rc = eig_plan_create(h->n2, h->S, h->sweeps, true, &h->eig, h->rep, EIG_PLAN_TOP_HALF, h->status))) return rc;
-  if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq, nullptr, 0, h->status))) return rc;
-  if (h->n3 < h->n4 && (rc = eig_plan_create(h->n3, lanes, h->sweeps + 2, true, &h->eigq3, nullptr, 0, h->status))) return rc;
+  // the query reads the l largest pairs of its stacked Gram (order 4 l, or 3 l on a rotation boundary) with the same shrink
+  // rule as a rotation: orders the direct solver covers go to it
+  if ((rc = eig_plan_create(h->n4, lanes, h->sweeps + 2, true, &h->eigq, nullptr, EIG_PLAN_TOP_FD, h->status, ell))) return rc;
+  if (h->n3 < h->n4 &&
+      (rc = eig_plan_create(h->n3, lanes, h->sweeps + 2, true, &h->eigq3, nullptr, EIG_PLAN_TOP_FD, h->status, ell)))
+    return rc;
   {
     // input-block pre-rotation (swfd_prerotate): batches of `pre_chunk` blocks x lanes, workspace <= ~256 MB per array
     const char* pr = getenv("MUSED_SWFD_PREROT");

@@ -30,12 +30,16 @@ namespace mused {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int TN = 256, TM = 128, TNT = 512;
+// Certificate levels.  A significant vector must have a twisted-factorisation residual |(T - lam I) z| / (|z| |T|) <= TRD_RES_MAX
+// (measured: ~1e-16), a cosine <= TRD_COS_MAX with each of its 4 neighbours in the spectrum, and no 6 significant eigenvalues
+// may lie within max(1e-7 lam_0, TRD_GAP_PER_RES rmax |T|) (rmax = largest residual of the matrix): pairs 5 or more apart are
+// then separated by more than that width, which bounds their mutual contamination 2 rmax |T| / gap by 1e-8 -- the level the
+// neighbours are tested at and the parity tests assert (1e-8 sigma_1).
+constexpr double TRD_RES_MAX = 1e-13, TRD_COS_MAX = 1e-8, TRD_GAP_PER_RES = 2e8;
 // LDS map (doubles): persistent part, then a scratch region reused by the phases
 constexpr int L_D = 0, L_E = 256, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280, L_MISC = 1536, L_S = 1728;
 // phase A scratch
 constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][256] */, A_CP = 1792 /* [2][256] */, A_RED = 2304 /* [8] */, A_SQ = 2312 /* [2] */;
-// phase D scratch
-constexpr int D_VB = 0 /* [2][16][256] */, D_SP = 8192 /* [2][2][32][26] */;
 
 __host__ __device__ constexpr int tidx(int a, int b) { return a * (a + 1) / 2 + b; }
 
@@ -311,78 +315,6 @@ __device__ __forceinline__ int trd_sturm(const double2* __restrict__ dd2, double
   return cnt;
 }
 
-// ---- phase D: FOUR reflectors H_k0 H_k0+1 H_k0+2 H_k0+3 applied to the 256 x 128 eigenvector block per barrier ------------
-// Z <- H_0 H_1 H_2 H_3 Z (H_3 first).  With s_r = v_r^T Z (of the Z before the block) and g_rs = v_r^T v_s, the coefficient
-// rows are  c_3 = tau_3 s_3,  c_2 = tau_2 (s_2 - g_23 c_3),  c_1 = tau_1 (s_1 - g_12 c_2 - g_13 c_3),
-// c_0 = tau_0 (s_0 - g_01 c_1 - g_02 c_2 - g_03 c_3)  and  Z <- Z - sum_r v_r c_r: one reduction (16 + 6 sums per
-// thread column) and one barrier for four rank-1 updates.  KD = (k0 + 1) / 32: rows below 32 KD are untouched.
-constexpr int D_SPQ = 26;  // doubles per thread column in the partial-sum buffer (24 used; 26 keeps 16-byte reads conflict free)
-template <int KD>
-__device__ __forceinline__ void trd_block_dots(const double (&Z)[16][4], const double* __restrict__ vb, double* __restrict__ sp,
-                                               const int p, const int q, const int wp, const int l) {
-  double acc[24];
-#pragma unroll
-  for (int e = 0; e < 24; ++e) acc[e] = 0.0;
-#pragma unroll
-  for (int a = 2 * KD; a < 16; ++a) {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = vb[r * 256 + p + 16 * a];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[4 * r + cb] = fma(v[r], Z[a][cb], acc[4 * r + cb]);
-    acc[16] = fma(v[0], v[1], acc[16]);
-    acc[17] = fma(v[0], v[2], acc[17]);
-    acc[18] = fma(v[0], v[3], acc[18]);
-    acc[19] = fma(v[1], v[2], acc[19]);
-    acc[20] = fma(v[1], v[3], acc[20]);
-    acc[21] = fma(v[2], v[3], acc[21]);
-  }
-  // sum over the 8 lanes that differ in lane bits 3-5 (the thread rows of a wave), transposing: 24 -> 12 -> 6 -> 3 per lane
-#pragma unroll
-  for (int e = 0; e < 12; ++e) acc[e] = swap32_add(acc[e], acc[e + 12]);
-#pragma unroll
-  for (int e = 0; e < 6; ++e) acc[e] = swap16_add(acc[e], acc[e + 6]);
-  const bool h3 = (l & 8) != 0;
-#pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    const double keep = h3 ? acc[e + 3] : acc[e], send = h3 ? acc[e] : acc[e + 3];
-    acc[e] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
-  }
-  const int base = ((l >> 5) & 1) * 12 + ((l >> 4) & 1) * 6 + (h3 ? 3 : 0);
-  double* dst = sp + (wp * 32 + q) * D_SPQ + base;
-  dst[0] = acc[0];
-  dst[1] = acc[1];
-  dst[2] = acc[2];
-}
-template <int KD>
-__device__ __forceinline__ void trd_block_update(double (&Z)[16][4], const double* __restrict__ vb, const double* __restrict__ sp,
-                                                 const double* __restrict__ tau4, const int p, const int q) {
-  const double* s0 = sp + q * D_SPQ;
-  const double* s1 = sp + (32 + q) * D_SPQ;
-  auto sum2 = [&](int e) -> double { return s0[e] + s1[e]; };  // (the two thread-row halves of the workgroup)
-  const double t0 = tau4[0], t1 = tau4[1], t2 = tau4[2], t3 = tau4[3];
-  const double g01 = sum2(16), g02 = sum2(17), g03 = sum2(18), g12 = sum2(19), g13 = sum2(20), g23 = sum2(21);
-  double c[4][4];
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    c[3][cb] = t3 * sum2(12 + cb);
-    c[2][cb] = t2 * fma(-g23, c[3][cb], sum2(8 + cb));
-    c[1][cb] = t1 * fma(-g13, c[3][cb], fma(-g12, c[2][cb], sum2(4 + cb)));
-    c[0][cb] = t0 * fma(-g03, c[3][cb], fma(-g02, c[2][cb], fma(-g01, c[1][cb], sum2(cb))));
-  }
-#pragma unroll
-  for (int a = 2 * KD; a < 16; ++a) {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = vb[r * 256 + p + 16 * a];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-      Z[a][cb] = fma(-v[0], c[0][cb], fma(-v[1], c[1][cb], fma(-v[2], c[2][cb], fma(-v[3], c[3][cb], Z[a][cb]))));
-  }
-}
-
 // ---- workspace per matrix (doubles) --------------------------------------------------------------------------------
 constexpr long W_HS = 0;                        // 256 x 256 Householder vectors (row k = v_k)
 constexpr long W_ZG = W_HS + (long)TN * TN;     // 256 x 128 eigenvectors of T, unnormalised ([i][c])
@@ -392,25 +324,59 @@ constexpr long W_MI = W_LG + 3 * TM;            // {|T|, pivmin, bad flag (int),
 constexpr long W_TM = W_MI + 16;                // 16 blocks x (16 x 16) triangular factors of the blocked reflectors
 constexpr long W_PER = W_TM + 16 * 256;
 
+// Shape of a solve.  Orders n < 256 are EMBEDDED at the bottom right of the 256-layout (rows / columns [off, 256), off =
+// 256 - n): the first `off` Householder steps are identities and are skipped, and the steps that run start with the register
+// blocks above / left of the matrix already inactive (K = k / 32) -- an order-n solve costs what the last n columns of an
+// order-256 solve cost.  T then has `off` leading zero rows (decoupled zero eigenvalues: the Gram matrices here are PSD).
+struct TrdShape {
+  int n, ldn, off;  // order, leading dimension of the matrices in Gc (column-major, n <= ldn <= 256), 256 - n
+  int nvec;         // eigenpairs formed: a multiple of 32, <= 128
+  int need;         // the caller reads the `need` largest pairs (<= nvec)
+  int cert_all;     // 1: every pair below `need` with lam > 1e-24 lam_0 is certified (the eigenstep uses all of them);
+                    // 0: the pairs whose energy survives the FD shrink by lam_{need-1} (discard level 1e-10 lam_0)
+};
+
+// Which of the computed pairs the certificate covers (kernels C and D agree on this).
+__device__ __forceinline__ bool trd_significant(double lc, int c, double lam0, double lamcut, const TrdShape& sh) {
+  if (c >= sh.need || !(lc > 0.0)) return false;
+  const double l0 = lam0 > 0.0 ? lam0 : 0.0;
+  return sh.cert_all ? (lc > 1e-24 * l0) : ((lc - lamcut) > 1e-10 * l0);
+}
+
 struct TrdDebug {
   long long* clk;            // TRD_STEP_PROFILE: batch x 16, cycles per part of a phase-A step in [8 .. 13]
   unsigned long long* work;  // profiling: += 1 per matrix this launch solved (not skipped, not rejected)
 };
 
 // ================= kernel A: tridiagonalisation (one workgroup = one CU per matrix) =================
+// EMB = false: order 256 exactly (off = 0, ldn = 256: constant addressing, every step runs); true: an embedded order.
+template <bool EMB>
 __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
-                                                       double* __restrict__ ws, TrdDebug dbg) {
+                                                       double* __restrict__ ws, TrdDebug dbg, const TrdShape sh) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
   if (rep && rep[bm] != bm) return;  // duplicate of another matrix / frozen sketch: nothing to solve
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   const int wp = w >> 2, wq = w & 3, lp = l & 7, lq = l >> 3;  // (lq in the lane bits the v_permlane swaps reach)
   const int p = wp * 8 + lp, q = wq * 8 + lq;
-  const double* G = Gc + (long)bm * TN * TN;
+  const int off = EMB ? sh.off : 0, ldn = EMB ? sh.ldn : TN;
+  const double* G = Gc + (long)bm * ldn * ldn;
   double* wsm = ws + (long)bm * W_PER;
   double* Hs = wsm + W_HS;
   double* S = sm + L_S;
   double A[2][36];
+  const double* Gsrc = G;
+  if constexpr (EMB) {
+    // the matrix is first copied into the 256-layout (entry (i, j) of the order-n matrix at (i + off, j + off), zeros
+    // above / left of it), in the workspace region the Householder vectors will overwrite step by step -- every load below
+    // has completed by then -- so that the register load keeps its constant addressing
+    for (int e = t; e < TN * TN; e += TNT) {
+      const int j = e >> 8, i = e & 255;
+      Hs[e] = (j >= off && i >= off) ? G[(long)(j - off) * ldn + (i - off)] : 0.0;
+    }
+    __syncthreads();  // (global writes of this workgroup are visible to it behind the barrier)
+    Gsrc = Hs;
+  }
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -418,16 +384,24 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
         const int i = p + 16 * u + 32 * a, j = q + 32 * b;
-        A[u][tidx(a, b)] = G[(long)j * TN + i] * (a == b ? 0.5 : 1.0);
+        A[u][tidx(a, b)] = Gsrc[(long)j * TN + i] * (a == b ? 0.5 : 1.0);
       }
   for (int i = t; i < 768; i += TNT) S[A_XS + i] = 0.0;
+  if (EMB) {
+    __syncthreads();  // every thread has its elements: the rows of Hs may be rewritten
+    if (t < off) {  // the skipped steps: identity reflectors, zero rows of T
+      sm[L_D + t] = 0.0;
+      sm[L_E + t] = 0.0;
+      sm[L_TAU + t] = 0.0;
+    }
+    // the block of 16 reflectors that straddles `off` is read whole by the back-transformation: its skipped rows are zeros
+    for (int i = t; i < (off & 15) * TN; i += TNT) Hs[(long)(off & ~15) * TN + i] = 0.0;
+  }
   __syncthreads();
   long long prof[6] = {0, 0, 0, 0, 0, 0};
 #define TRD_RUN(KV)                                                                           \
-  for (int kk_ = 0; kk_ < 32; ++kk_) {                                                        \
-    const int k_ = 32 * (KV) + kk_;                                                           \
-    if (k_ <= TN - 2) trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs, prof);                     \
-  }
+  for (int k_ = (EMB && off > 32 * (KV)) ? off : 32 * (KV); k_ < 32 * (KV) + 32 && k_ <= TN - 2; ++k_) \
+    trd_step<KV>(A, k_, sm, t, p, q, wp, wq, Hs, prof);
   TRD_RUN(0) TRD_RUN(1) TRD_RUN(2) TRD_RUN(3) TRD_RUN(4) TRD_RUN(5) TRD_RUN(6) TRD_RUN(7)
 #undef TRD_RUN
 #ifdef TRD_STEP_PROFILE
@@ -452,8 +426,9 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
 // points itself).  Both variants evaluate the same points in the same arithmetic: the eigenvalues do not depend on the
 // batch size (lock-step lanes == single sketches bit for bit).
 template <int NTB>
-__global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
-  constexpr int NCH = TNT / NTB, NWV = NTB / 64;
+__global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
+  constexpr int NWV = NTB / 64;
+  const int NCH = NTB == TNT ? 1 : sh.nvec / (NTB / 4);  // workgroups per matrix (NTB / 4 eigenvalues each)
   constexpr int PASSES = 19, NPT = 512;  // 5^19 x 513 > 2^53
   __shared__ __attribute__((aligned(16))) double2 dd2[TN + 8];
   __shared__ double part[3 * NWV];
@@ -511,6 +486,7 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
   for (int i = t; i < NPT; i += NTB) cnts[i] = trd_sturm(dd2, fma(h0, (double)(i + 1), gl));
   __syncthreads();
   const int r = cq * (NTB / 4) + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
+  if (r >= sh.nvec) return;  // (whole quads, and no barrier follows)
   int first = 0;  // smallest point index whose count exceeds jidx (NPT: none) -- counts are non-decreasing
   for (int step = NPT / 2; step > 0; step >>= 1)
     if (first + step <= NPT && cnts[first + step - 1] <= jidx) first += step;
@@ -536,14 +512,15 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
 // and the part below (two dependent chains of 255 divisions side by side); lane c < 32 of either wave = vector cq * 32 + c.
 // The pivot sequences of the 32 vectors stay in LDS ([i][vector], 2 x 64 KB: one workgroup per CU); every stretch of a
 // dependent chain is preceded by its batch of loads.
-__global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+__global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
   extern __shared__ __attribute__((aligned(16))) double smc[];  // C_LDS doubles
   double2* dd2 = reinterpret_cast<double2*>(smc);  // [TN]
   double* es = smc + 2 * TN;                       // [TN]
   double* xch = es + TN;                           // [32 * 4]
   double* qp = xch + 128;                          // forward pivots [TN][32]
   double* qm = qp + TN * 32;                       // backward pivots [TN][32]
-  const int bm = blockIdx.x >> 2, cq = blockIdx.x & 3;
+  const int nch = sh.nvec >> 5;  // workgroups per matrix
+  const int bm = blockIdx.x / nch, cq = blockIdx.x - bm * nch;
   if (rep && rep[bm] != bm) return;
   const int t = threadIdx.x, role = t >> 6, l = t & 63;
   double* wsm = ws + (long)bm * W_PER;
@@ -557,7 +534,7 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
   }
   __syncthreads();
   const double tnorm = wsm[W_MI], pivmin = wsm[W_MI + 1];
-  const double lam0 = wsm[W_LG], lamcut = wsm[W_LG + TM - 1];
+  const double lam0 = wsm[W_LG], lamcut = wsm[W_LG + sh.need - 1];
   const bool act = l < 32;
   const int cl = l & 31, c = cq * 32 + cl;  // (pivot arrays: column cl of this workgroup's 32)
   const double lam = wsm[W_LG + c];
@@ -670,134 +647,8 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
     wsm[W_LG + TM + c] = zs;
     const double res = gbest * zs / (tnorm > 0.0 ? tnorm : 1.0);
     wsm[W_LG + 2 * TM + c] = res;
-    const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
-    const bool sig = lam > 0.0 && (lam - lamcut) > sigtol;
-    if (sig && !(ss < 1e300 && res <= 1e-11)) atomicOr(reinterpret_cast<int*>(wsm + W_MI + 2), 1);
-  }
-}
-
-// ================= kernel D (vector-ALU variant, MUSED_TRD_BACK=valu): certificate, then V = Q Z =================
-__global__ __launch_bounds__(TNT, 1) void trd_d_valu_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
-                                                       int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int bm = blockIdx.x;
-  if (rep && rep[bm] != bm) {  // (the Jacobi skips it too)
-    if (threadIdx.x == 0) done[bm] = 1;
-    return;
-  }
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  const int wp = w >> 2, wq = w & 3, lp = l >> 3, lq = l & 7;
-  const int p = wp * 8 + lp, q = wq * 8 + lq;
-  double* G = Gc + (long)bm * TN * TN;
-  double* wsm = ws + (long)bm * W_PER;
-  const double* Hs = wsm + W_HS;
-  const double* Zg = wsm + W_ZG;
-  double* S = sm + L_S;
-  int* badflag = reinterpret_cast<int*>(sm + L_MISC + 8);
-  if (t < TN) sm[L_TAU + t] = wsm[W_TG + 2 * TN + t];
-  if (t < TM) {
-    sm[L_LAM + t] = wsm[W_LG + t];
-    sm[L_ZS + t] = wsm[W_LG + TM + t];
-  }
-  if (t == 0) *badflag = reinterpret_cast<const int*>(wsm + W_MI + 2)[0];
-  __syncthreads();
-  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1];
-  const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
-  auto significant = [&](int c) -> bool { const double lc = sm[L_LAM + c]; return lc > 0.0 && (lc - lamcut) > sigtol; };
-  // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
-  {
-    const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
-    if (c2 < TM && significant(c) && significant(c2)) {
-      double dotv = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
-      if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= 1e-8)) atomicOr(badflag, 2);
-    }
-    if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5) &&
-        (sm[L_LAM + c] - sm[L_LAM + c + 5]) <= 1e-7 * lam0)
-      atomicOr(badflag, 4);
-  }
-  __syncthreads();
-  if (*badflag) {  // leave G as it is: the Jacobi solver takes this matrix
-    if (t == 0) done[bm] = 0;
-    return;
-  }
-  double Z[16][4];
-#pragma unroll
-  for (int a = 0; a < 16; ++a)
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) Z[a][cb] = Zg[(long)(p + 16 * a) * TM + q + 32 * cb] * sm[L_ZS + q + 32 * cb];
-  // Reflectors are staged in LDS in blocks of 16 (the next block travels from global memory into registers while the
-  // current one is applied), four are applied per barrier (trd_block_dots / trd_block_update).
-  constexpr int DBK = 16;
-  double* vblk = S + D_VB;   // [2][DBK][256]
-  double* spb = S + D_SP;    // [2][2][32][D_SPQ]
-  auto block_fetch = [&](int kb, double (&nx)[8]) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int idx = t + TNT * m, kr = DBK * kb + (idx >> 8);
-      nx[m] = (kb >= 0 && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
-    }
-  };
-  auto block_store = [&](int buf, const double (&nx)[8]) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) vblk[buf * (DBK * 256) + t + TNT * m] = nx[m];
-  };
-  double nx[8];
-  const int kb_top = (TN - 3) / DBK;
-  block_fetch(kb_top, nx);
-  block_store(0, nx);
-  __syncthreads();
-  int par = 0;
-  for (int kb = kb_top; kb >= 0; --kb) {
-    const int buf = (kb_top - kb) & 1;
-    block_fetch(kb - 1, nx);
-    for (int k4 = DBK / 4 - 1; k4 >= 0; --k4) {
-      const int k0 = DBK * kb + 4 * k4;  // reflectors k0 .. k0 + 3 (beyond TN - 3: zero vectors, tau = 0)
-      const double* tau4 = sm + L_TAU + k0;
-      if (tau4[0] == 0.0 && tau4[1] == 0.0 && tau4[2] == 0.0 && tau4[3] == 0.0) continue;  // uniform
-      const double* vb = vblk + buf * (DBK * 256) + 4 * k4 * 256;
-      double* sp = spb + par * (2 * 32 * D_SPQ);
-      switch ((k0 + 1) >> 5) {
-        case 0: trd_block_dots<0>(Z, vb, sp, p, q, wp, l); break;
-        case 1: trd_block_dots<1>(Z, vb, sp, p, q, wp, l); break;
-        case 2: trd_block_dots<2>(Z, vb, sp, p, q, wp, l); break;
-        case 3: trd_block_dots<3>(Z, vb, sp, p, q, wp, l); break;
-        case 4: trd_block_dots<4>(Z, vb, sp, p, q, wp, l); break;
-        case 5: trd_block_dots<5>(Z, vb, sp, p, q, wp, l); break;
-        case 6: trd_block_dots<6>(Z, vb, sp, p, q, wp, l); break;
-        default: trd_block_dots<7>(Z, vb, sp, p, q, wp, l); break;
-      }
-      lds_barrier();
-      switch ((k0 + 1) >> 5) {
-        case 0: trd_block_update<0>(Z, vb, sp, tau4, p, q); break;
-        case 1: trd_block_update<1>(Z, vb, sp, tau4, p, q); break;
-        case 2: trd_block_update<2>(Z, vb, sp, tau4, p, q); break;
-        case 3: trd_block_update<3>(Z, vb, sp, tau4, p, q); break;
-        case 4: trd_block_update<4>(Z, vb, sp, tau4, p, q); break;
-        case 5: trd_block_update<5>(Z, vb, sp, tau4, p, q); break;
-        case 6: trd_block_update<6>(Z, vb, sp, tau4, p, q); break;
-        default: trd_block_update<7>(Z, vb, sp, tau4, p, q); break;
-      }
-      par ^= 1;
-    }
-    block_store(buf ^ 1, nx);
-    lds_barrier();
-  }
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    const int c = q + 32 * cb;
-    const double lc = sm[L_LAM + c];
-    const double f = lc > 0.0 ? lc : 0.0;
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-      G[(long)c * TN + p + 16 * a] = f * Z[a][cb];
-      G[(long)(c + TM) * TN + p + 16 * a] = 0.0;
-    }
-  }
-  if (t == 0) {
-    done[bm] = 1;
-    if (dbg.work) atomicAdd(dbg.work, 1ull);
+    if (trd_significant(lam, c, lam0, lamcut, sh) && !(ss < 1e300 && res <= TRD_RES_MAX))
+      atomicOr(reinterpret_cast<int*>(wsm + W_MI + 2), 1);
   }
 }
 
@@ -806,11 +657,12 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_valu_kernel(double* __restrict__
 // forward / columnwise):  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i).  One wave per block: V^T V by 64 MFMAs
 // (both operands of an instruction are the same register: lane (kq, li) holds V[row 4 s + kq][reflector li]), then the
 // 16 columns of T one after the other, row i on lane i.
-__global__ __launch_bounds__(64) void trd_t_kernel(const int* __restrict__ rep, double* __restrict__ ws) {
+__global__ __launch_bounds__(64) void trd_t_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
   __shared__ double Gs[16][17];
   __shared__ double Ts[16][17];
   const int bm = blockIdx.x >> 4, kb = blockIdx.x & 15;
   if (rep && rep[bm] != bm) return;
+  if (16 * kb + 15 < sh.off) return;  // identity reflectors of an embedded order: kernel D skips the block as well
   double* wsm = ws + (long)bm * W_PER;
   const double* Hs = wsm + W_HS;
   const int l = threadIdx.x, kq = l >> 4, li = l & 15;
@@ -864,7 +716,8 @@ constexpr int DM_VB = 4096;              // [16][272]   V as [reflector][row]
 constexpr int DM_TM = DM_VB + 16 * 272;  // [16][16]    T
 constexpr int DM_TOTAL = DM_TM + 256;
 __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
-                                                       int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg) {
+                                                       int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg,
+                                                       const TrdShape sh) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
   if (rep && rep[bm] != bm) {  // (the Jacobi skips it too)
@@ -873,7 +726,8 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
   }
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   const int kq = l >> 4, li = l & 15;
-  double* G = Gc + (long)bm * TN * TN;
+  const int off = sh.off, ldn = sh.ldn, n = sh.n;
+  double* G = Gc + (long)bm * ldn * ldn;
   double* wsm = ws + (long)bm * W_PER;
   const double* Hs = wsm + W_HS;
   const double* Zg = wsm + W_ZG;
@@ -882,24 +736,27 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
   if (t < TM) {
     sm[L_LAM + t] = wsm[W_LG + t];
     sm[L_ZS + t] = wsm[W_LG + TM + t];
+    sm[L_D + t] = wsm[W_LG + 2 * TM + t];  // residuals (kernel C)
   }
   if (t == 0) *badflag = reinterpret_cast<const int*>(wsm + W_MI + 2)[0];
   __syncthreads();
-  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + TM - 1];
-  const double sigtol = 1e-10 * (lam0 > 0.0 ? lam0 : 0.0);
-  auto significant = [&](int c) -> bool { const double lc = sm[L_LAM + c]; return lc > 0.0 && (lc - lamcut) > sigtol; };
+  const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + sh.need - 1];
+  auto significant = [&](int c) -> bool { return c < sh.nvec && trd_significant(sm[L_LAM + c], c, lam0, lamcut, sh); };
   // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
   {
     const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
     if (c2 < TM && significant(c) && significant(c2)) {
       double dotv = 0.0;
 #pragma unroll 8
-      for (int i = 0; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
-      if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= 1e-8)) atomicOr(badflag, 2);
+      for (int i = off; i < TN; ++i) dotv = fma(Zg[(long)i * TM + c], Zg[(long)i * TM + c2], dotv);
+      if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= TRD_COS_MAX)) atomicOr(badflag, 2);
     }
-    if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5) &&
-        (sm[L_LAM + c] - sm[L_LAM + c + 5]) <= 1e-7 * lam0)
-      atomicOr(badflag, 4);
+    if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5)) {
+      double rmax = 0.0;  // largest residual among the significant vectors
+      for (int j = 0; j < sh.nvec; ++j) rmax = (significant(j) && sm[L_D + j] > rmax) ? sm[L_D + j] : rmax;
+      const double width = fmax(1e-7 * lam0, TRD_GAP_PER_RES * rmax * wsm[W_MI]);
+      if ((sm[L_LAM + c] - sm[L_LAM + c + 5]) <= width) atomicOr(badflag, 4);
+    }
   }
   __syncthreads();
   if (*badflag) {  // leave G as it is: the Jacobi solver takes this matrix
@@ -908,25 +765,27 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
   }
   // Z tiles of this wave: column 16 w + li, rows 16 T + kq + 4 r
   const int col = 16 * w + li;
+  const bool wact = 16 * w < sh.nvec;  // (nvec is a multiple of 32: a wave's 16 columns are all formed or none is)
   v4f64 Zt[16];
   {
-    const double zs = sm[L_ZS + col];
+    const double zs = wact ? sm[L_ZS + col] : 0.0;
 #pragma unroll
     for (int T = 0; T < 16; ++T)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Zt[T][r] = Zg[(long)(16 * T + kq + 4 * r) * TM + col] * zs;
+      for (int r = 0; r < 4; ++r) Zt[T][r] = wact ? Zg[(long)(16 * T + kq + 4 * r) * TM + col] * zs : 0.0;
   }
   double* vA = S + DM_VA;
   double* vB = S + DM_VB;
   double* tm = S + DM_TM;
   // staging of a block: 16 reflectors x 256 rows = 8 values per thread (coalesced along the row), T: 256 values
+  const int kb_lo = off >> 4;  // blocks below hold identity reflectors only (embedded order)
   auto fetch = [&](int kb, double (&nx)[8], double& tx) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int idx = t + TNT * m, kr = 16 * kb + (idx >> 8);
-      nx[m] = (kb >= 0 && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
+      nx[m] = (kb >= kb_lo && kr <= TN - 3) ? Hs[(long)kr * TN + (idx & 255)] : 0.0;
     }
-    tx = (kb >= 0 && t < 256) ? wsm[W_TM + kb * 256 + t] : 0.0;
+    tx = (kb >= kb_lo && t < 256) ? wsm[W_TM + kb * 256 + t] : 0.0;
   };
   auto store = [&](const double (&nx)[8], double tx) {
 #pragma unroll
@@ -942,9 +801,9 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
   fetch(kb_top, nx, tx);
   store(nx, tx);
   __syncthreads();
-  for (int kb = kb_top; kb >= 0; --kb) {
+  for (int kb = kb_top; kb >= kb_lo; --kb) {
     fetch(kb - 1, nx, tx);
-    const int Tlo = (16 * kb + 1) >> 4;  // row tiles below hold no entry of these reflectors
+    const int Tlo = wact ? (16 * kb + 1) >> 4 : 16;  // row tiles below hold no entry of these reflectors
     // S = V^T Z_w : M = reflector, K = row, N = column
     v4f64 Sa = {0.0, 0.0, 0.0, 0.0}, Sb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -978,15 +837,27 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
     __syncthreads();
   }
   {
-    const double lc = sm[L_LAM + col];
+    // column c of the result: rows [0, n) = lam_c v_c (the embedded rows [off, 256) moved up), everything else of the
+    // ldn x ldn matrix zeros
+    const int ncol = n < sh.nvec ? n : sh.nvec;
+    const bool cval = col < ncol;
+    const double lc = cval ? sm[L_LAM + col] : 0.0;
     const double f = lc > 0.0 ? lc : 0.0;
 #pragma unroll
     for (int T = 0; T < 16; ++T)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        G[(long)col * TN + 16 * T + kq + 4 * r] = f * Zt[T][r];
-        G[(long)(col + TM) * TN + 16 * T + kq + 4 * r] = 0.0;
+        const int i = 16 * T + kq + 4 * r - off;
+        if (i >= 0) {
+          if (col < ldn) G[(long)col * ldn + i] = cval ? f * Zt[T][r] : 0.0;
+          if (col + TM < ldn) G[(long)(col + TM) * ldn + i] = 0.0;
+        }
       }
+    const int npad = ldn - n;  // padding rows of the Jacobi's layout
+    for (int idx = t; idx < npad * ldn; idx += TNT) {
+      const int c = idx / npad;
+      G[(long)c * ldn + n + (idx - c * npad)] = 0.0;
+    }
   }
   if (t == 0) {
     done[bm] = 1;
@@ -1001,17 +872,14 @@ namespace mused {
 size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; }
 
 constexpr int L_A_TOTAL = L_S + 2314;            // kernel A: persistent part + its scratch
-constexpr int L_D_TOTAL = L_S + D_SP + 2 * 2 * 32 * D_SPQ;  // kernel D (vector-ALU variant): reflector blocks + partial sums
-constexpr int L_DM_TOTAL = L_S + DM_TOTAL;                  // kernel D (matrix-core variant)
+constexpr int L_DM_TOTAL = L_S + DM_TOTAL;       // kernel D
 constexpr int C_LDS = 2 * TN + TN + 128 + 2 * TN * 32;       // kernel C: T, exchange, the pivot sequences of 32 vectors
 
 int trd_prepare() {
   static std::once_flag once;
   static hipError_t rc = hipSuccess;
   std::call_once(once, [] {
-    rc = hipFuncSetAttribute((const void*)trd_d_valu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_D_TOTAL));
-    if (rc == hipSuccess)
-      rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_DM_TOTAL));
+    rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_DM_TOTAL));
     if (rc == hipSuccess)
       rc = hipFuncSetAttribute((const void*)trd_c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * C_LDS));
   });
@@ -1019,27 +887,31 @@ int trd_prepare() {
   return MUSED_OK;
 }
 
-// Solves the matrices of Gc (batch x 256 x 256, symmetric) in place: done[b] = 1 -> columns 0 .. 127 of matrix b hold
-// lam_j v_j for its 128 largest eigenvalues (descending), columns 128 .. 255 zeros; done[b] = 0 -> untouched (certificate
-// failed: solve it with the Jacobi).  ws: trd_workspace_doubles(batch) doubles.  Four launches on `st`.
-int trd_solve(double* Gc, int batch, const int* rep, int* done, double* ws, hipStream_t st, long long* dbg_clk,
-              unsigned long long* work, hipEvent_t after_a) {
+bool trd_supports(int n, int ldn, int need) { return n >= 2 && n <= TN && ldn >= n && ldn <= TN && need >= 1 && need <= TM && need <= n; }
+
+// Solves the matrices of Gc (batch x ldn x ldn column-major, symmetric of order n <= ldn <= 256, zero padded) in place:
+// done[b] = 1 -> columns 0 .. min(n, nvec) - 1 of matrix b hold lam_j v_j for its largest eigenvalues (descending; nvec = `need`
+// rounded up to a multiple of 32), every other entry zeros; done[b] = 0 -> untouched (certificate failed: solve it with the
+// Jacobi).  `need`: how many leading pairs the caller reads; cert_all: see TrdShape.  ws: trd_workspace_doubles(batch)
+// doubles.  Five launches on `st`.
+int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
+              hipStream_t st, long long* dbg_clk, unsigned long long* work, hipEvent_t after_a) {
+  MUSED_REQUIRE(trd_supports(n, ldn, need), "trd_solve: unsupported shape (n=%d, ld=%d, need=%d)", n, ldn, need);
   TrdDebug dbg{dbg_clk, work};
-  hipLaunchKernelGGL(trd_a_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg);
+  TrdShape sh;
+  sh.n = n; sh.ldn = ldn; sh.off = TN - n;
+  sh.nvec = ((need + 31) / 32) * 32;
+  sh.need = need;
+  sh.cert_all = cert_all ? 1 : 0;
+  const int nch = sh.nvec / 32;
+  if (n == TN && ldn == TN) hipLaunchKernelGGL(trd_a_kernel<false>, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg, sh);
+  else hipLaunchKernelGGL(trd_a_kernel<true>, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg, sh);
   if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));  // profiling: the tridiagonalisation alone
-  if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(4 * batch), dim3(128), 0, st, rep, ws);
-  else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws);
-  hipLaunchKernelGGL(trd_c_kernel, dim3(4 * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws);
-  static const bool back_valu = [] {
-    const char* e = getenv("MUSED_TRD_BACK");
-    return e && e[0] == 'v';
-  }();
-  if (back_valu) {
-    hipLaunchKernelGGL(trd_d_valu_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_D_TOTAL, st, Gc, rep, done, ws, dbg);
-  } else {
-    hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(64), 0, st, rep, ws);
-    hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg);
-  }
+  if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(nch * batch), dim3(128), 0, st, rep, ws, sh);
+  else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws, sh);
+  hipLaunchKernelGGL(trd_c_kernel, dim3(nch * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws, sh);
+  hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(64), 0, st, rep, ws, sh);
+  hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg, sh);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }
@@ -1061,19 +933,21 @@ __global__ void trd_export_kernel(const double* __restrict__ ws, double* __restr
 
 using namespace mused;
 
-// Diagnostic / unit-test entry (not part of the declared ABI): runs the direct solver alone on `batch` symmetric 256 x 256
-// matrices (device, overwritten as trd_solve does) and returns the intermediate quantities of every phase.
-// out_d / out_e: batch x 256 (tridiagonal), out_lam: batch x 128 (descending), out_res: batch x 128, out_done: batch ints.
-extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_e, double* out_lam, double* out_res,
-                               int* out_done, void* stream) {
+// Diagnostic / unit-test entry (not part of the declared ABI): runs the direct solver alone on `batch` symmetric n x n
+// matrices (device, column-major with leading dimension n, overwritten as trd_solve does) and returns the intermediate
+// quantities of every phase in the 256-layout (order n embedded at the bottom right: the first 256 - n entries of d / e are
+// zeros).  out_d / out_e: batch x 256 (tridiagonal), out_lam: batch x 128 (descending; the first `need` rounded up to 32 are
+// formed), out_res: batch x 128, out_done: batch ints.
+extern "C" int mused_debug_trd_n(double* G, int n, int need, int cert_all, int batch, double* out_d, double* out_e,
+                                 double* out_lam, double* out_res, int* out_done, void* stream) {
   MUSED_REQUIRE(G && batch >= 1 && out_done, "mused_debug_trd: bad arguments");
   int rc = trd_prepare();
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   double* ws = nullptr;
   MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trd_workspace_doubles(batch)));
-  rc = trd_solve(G, batch, nullptr, out_done, ws, st);
-  hipLaunchKernelGGL(trd_export_kernel, dim3(batch), dim3(TN), 0, st, ws, out_d, out_e, out_lam, out_res);
+  rc = trd_solve(G, n, n, need, cert_all != 0, batch, nullptr, out_done, ws, st);
+  if (!rc) hipLaunchKernelGGL(trd_export_kernel, dim3(batch), dim3(TN), 0, st, ws, out_d, out_e, out_lam, out_res);
   hipError_t e = hipStreamSynchronize(st);
   (void)hipFree(ws);
   if (rc) return rc;
@@ -1081,17 +955,22 @@ extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_
   return MUSED_OK;
 }
 
-// Diagnostic: average time (ms, HIP events) of `reps` direct solves of the same `batch` matrices (G is restored from a
-// copy before every solve; the copy is outside the timed region).
-extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double* out_ms, int* out_done, long long* out_clk,
-                                    void* stream) {
+extern "C" int mused_debug_trd(double* G, int batch, double* out_d, double* out_e, double* out_lam, double* out_res,
+                               int* out_done, void* stream) {
+  return mused_debug_trd_n(G, TN, TM, 0, batch, out_d, out_e, out_lam, out_res, out_done, stream);
+}
+
+// Diagnostic: average time (ms, HIP events) of `reps` direct solves of the same `batch` matrices of order n (G is restored
+// from a copy before every solve; the copy is outside the timed region).
+extern "C" int mused_debug_trd_time_n(const double* G, int n, int need, int batch, int reps, double* out_ms, int* out_done,
+                                      long long* out_clk, void* stream) {
   MUSED_REQUIRE(G && batch >= 1 && reps >= 1 && out_ms, "mused_debug_trd_time: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int rc = trd_prepare();
   if (rc) return rc;
   double *ws = nullptr, *work = nullptr;
   int* done = nullptr;
-  const size_t bytes = sizeof(double) * (size_t)batch * TN * TN;
+  const size_t bytes = sizeof(double) * (size_t)batch * n * n;
   MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trd_workspace_doubles(batch)));
   MUSED_CHECK_HIP(hipMalloc((void**)&work, bytes));
   MUSED_CHECK_HIP(hipMalloc((void**)&done, sizeof(int) * (size_t)batch));
@@ -1102,7 +981,7 @@ extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double
   for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
     MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
     MUSED_CHECK_HIP(hipEventRecord(e0, st));
-    rc = trd_solve(work, batch, nullptr, done, ws, st, out_clk);
+    rc = trd_solve(work, n, n, need, false, batch, nullptr, done, ws, st, out_clk);
     MUSED_CHECK_HIP(hipEventRecord(e1, st));
     MUSED_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -1115,4 +994,9 @@ extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double
   (void)hipEventDestroy(e1);
   (void)hipFree(ws); (void)hipFree(work); (void)hipFree(done);
   return rc;
+}
+
+extern "C" int mused_debug_trd_time(const double* G, int batch, int reps, double* out_ms, int* out_done, long long* out_clk,
+                                    void* stream) {
+  return mused_debug_trd_time_n(G, TN, TM, batch, reps, out_ms, out_done, out_clk, stream);
 }

@@ -353,6 +353,9 @@ def main():
             case_bench_stream("bench_c3_blob_s0", "blob", 8, 10000, 4096, 256, 50, 0)
         if "bench_c4_blob_s0" in only:   # bench.py --workload c4: 8 windows of BASELINE config 4 (two 512-d modalities)
             case_bench_stream("bench_c4_blob_s0", "blob", 8, 10000, 1024, 128, 50, 0, dims=(512, 512))
+        if "refdef_blob_s0" in only:   # the reference's OWN default parameters (main.py:305-313): W = 2000, reduced_dim = 50, k = 50
+            case_windows("refdef_blob_s0", "blob", 2000, 256, 2000, 50, 50, 0, n_centres=8, sep=2.0)
+            case_bench_stream("bench_refdef_blob_s0", "blob", 10, 2000, 256, 50, 50, 0)
         if "c3_blob_s0" in only:   # BASELINE config 3 at its real shape
             case_windows("c3_blob_s0", "blob", 10000, 4096, 10000, 256, 50, 0, n_centres=8, sep=2.0)
         if "c4_twomod_s0" in only:  # BASELINE config 4 at its real shape (one of the 8 windows)
@@ -375,6 +378,10 @@ def main():
     case_stream("c4s_stream_twomod_s0", "blob2", 2048, 32, 512, 16, 20, 0, two_mod=True, n_centres=4)
     # a mid-size window in the C2 aspect ratio that the CPU suite can afford
     case_windows("c2m_blob_s0", "blob", 2000, 256, 2000, 64, 50, 0, n_centres=8, sep=2.0)
+    # the reference's own operating point (main.py:305-313: window_size 2000, reduced_dim 50, k_basis 50): one window record
+    # and ten windows through its window loop (approach sSVDMC)
+    case_windows("refdef_blob_s0", "blob", 2000, 256, 2000, 50, 50, 0, n_centres=8, sep=2.0)
+    case_bench_stream("bench_refdef_blob_s0", "blob", 10, 2000, 256, 50, 50, 0)
     if args.big:
         case_windows("c2_blob_s0", "blob", 10000, 1024, 10000, 128, 50, 0, n_centres=8, sep=2.0)
         case_windows("c2_gauss_s0", "gauss", 10000, 1024, 10000, 128, 50, 0)

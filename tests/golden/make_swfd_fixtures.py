@@ -53,5 +53,14 @@ def case(tag, W, dims, ell, k, seed, n_windows):
 
 
 if __name__ == "__main__":
-    case("swfdmc_w10k_m1", 10000, (64,), 128, 50, 0, 1)
-    case("swfdmc_w10k_m2", 10000, (32, 32), 128, 50, 0, 1)
+    only = sys.argv[1:]  # optional: tags to (re)generate
+    cases = [
+        ("swfdmc_w10k_m1", 10000, (64,), 128, 50, 0, 1),
+        ("swfdmc_w10k_m2", 10000, (32, 32), 128, 50, 0, 1),
+        # three windows: crosses the AUX -> MAIN swap at both epoch starts, the expiry of the first window's snapshots and
+        # two Hungarian matching steps at d = W = 10,000 (round 4; ~30 CPU-minutes)
+        ("swfdmc_w10k_m1_3win", 10000, (64,), 128, 50, 0, 3),
+    ]
+    for c in cases:
+        if not only or c[0] in only:
+            case(*c)

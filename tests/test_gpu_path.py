@@ -28,7 +28,9 @@ def _bool_from_adj(adj):
     return bits[:, : adj.n].astype(bool)
 
 
-WINDOW_CASES = ["c1_gauss_s0", "c1_gauss_s1", "c1_blob_s0", "c1_blob_s1", "c1_fd_s0", "c4s_twomod_s0", "c2m_blob_s0"]
+# refdef_blob_s0: the reference's own default parameters (/root/reference/main.py:305-313: W = 2000, reduced_dim 50, k 50)
+WINDOW_CASES = ["c1_gauss_s0", "c1_gauss_s1", "c1_blob_s0", "c1_blob_s1", "c1_fd_s0", "c4s_twomod_s0", "c2m_blob_s0",
+                "refdef_blob_s0"]
 
 
 @pytest.mark.parametrize("name", WINDOW_CASES)
@@ -263,6 +265,33 @@ def test_rsvd_intermediate_components(eng):
     np.testing.assert_allclose(sig.cpu().numpy(), s_ref, rtol=1e-10)
     np.testing.assert_allclose(comp.cpu().numpy(), vt_ref.T, atol=1e-8)
     np.testing.assert_allclose(emb.cpu().numpy(), e_ref, atol=1e-8 * np.abs(e_ref).max())
+
+
+@pytest.mark.parametrize("ell", [134, 137, 138, 276])
+def test_rsvd_two_block_cholesky_qr_sizes(ell):
+    """r = reduced_dim + 10 in (143, 286] takes the two-block Cholesky-QR, whose projection scratch sits behind the packed
+    factor: r = 144 .. 147 overran the workspace as round 3 sized it.  Singular values and embedding against the
+    oracle's LU / Householder chain at the boundary sizes r = 144, 147, 148, 286."""
+    from mused_amd import synth
+    from mused_amd.engine import WindowEngine
+    from oracle import mo_oracle as omo
+
+    n, k = 900, 30
+    X, _ = synth.blob_stream(n, 48, 5, n_centres=6)
+    e = WindowEngine(n)
+    try:
+        adj = e.knn_adjacency(torch.from_numpy(X).cuda(), k, "l2")
+        fused = e.fuse([adj])
+        emb, sig = e.svd_reduce(fused, ell, 3, nnz_cap=n * k)
+        flags, _ = e.rsvd_status()
+        assert flags == 0
+        F = omo.fuse_matrices([omo.create_adjacency_matrix(X.astype(np.float64), "", k)])
+        e_ref, s_ref, _ = omo.randomized_svd_reduce(F, ell, 3)
+        np.testing.assert_allclose(sig.cpu().numpy(), s_ref, rtol=1e-8)
+        big = s_ref > 1e-6 * s_ref[0]
+        np.testing.assert_allclose(emb.cpu().numpy()[:, big], e_ref[:, big], atol=1e-7 * np.abs(e_ref).max())
+    finally:
+        e.close()
 
 
 def test_rsvd_tiny_window_more_random_columns_than_rows(eng):

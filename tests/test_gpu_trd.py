@@ -59,6 +59,27 @@ def run_trd(Gs):
     return G.cpu().numpy(), d.cpu().numpy(), e.cpu().numpy(), lam.cpu().numpy(), res.cpu().numpy(), done.cpu().numpy()
 
 
+def run_trd_n(Gs, n, need, cert_all=0):
+    """The solver on matrices of order n <= 256 (embedded at the bottom right of the 256-layout, see csrc/trd.hip)."""
+    from mused_amd import _lib
+    from mused_amd.engine import ptr, stream_ptr
+
+    L = _lib.lib()
+    fn = L.mused_debug_trd_n
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+    B = len(Gs)
+    G = torch.from_numpy(np.ascontiguousarray(np.stack(Gs))).cuda()
+    d = torch.zeros(B, 256, dtype=torch.float64, device="cuda")
+    e = torch.zeros(B, 256, dtype=torch.float64, device="cuda")
+    lam = torch.zeros(B, 128, dtype=torch.float64, device="cuda")
+    res = torch.zeros(B, 128, dtype=torch.float64, device="cuda")
+    done = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(fn(ptr(G), n, need, cert_all, B, ptr(d), ptr(e), ptr(lam), ptr(res), ptr(done), stream_ptr()))
+    torch.cuda.synchronize()
+    return G.cpu().numpy(), d.cpu().numpy(), e.cpu().numpy(), lam.cpu().numpy(), res.cpu().numpy(), done.cpu().numpy()
+
+
 def fd_buffers(kind, nblk, seed=0, ell=128, d=1024):
     """Gram matrices of successive FD rotation buffers [kept rows; new block; zero rows] of a synthetic stream."""
     from mused_amd import synth
@@ -190,3 +211,55 @@ def test_rejected_matrices_go_through_the_jacobi_fallback():
     _, _, Vt = np.linalg.svd(buf, full_matrices=False)
     # the kept rows span the top directions with the shrunk energies: compare B^T B with the SVD's
     np.testing.assert_allclose(B.T @ B, (Vt[:ell].T * ref ** 2) @ Vt[:ell], rtol=0, atol=1e-9 * lam[0])
+
+
+@pytest.mark.parametrize("n", [20, 32, 100, 128, 150, 200, 254, 256])
+def test_direct_solver_embedded_orders_match_lapack(n):
+    """Orders below 256 (the reference's own operating range: reduced_dim 10 .. 100 -> rotations of order 20 .. 200, queries
+    of order 30 .. 400; /root/reference/main.py:270,309) run embedded in the 256-layout: top n / 2 pairs of FD rotation
+    buffers against LAPACK, zero columns / rows everywhere else, same certificate."""
+    ell = n // 2
+    Gs = fd_buffers("blob", 4, ell=ell, d=max(64, 3 * n)) + fd_buffers("fd", 2, ell=ell, d=max(64, 3 * n), seed=1)
+    out, d, e, lam, res, done = run_trd_n(Gs, n, ell)
+    off = 256 - n
+    for b, G in enumerate(Gs):
+        w = np.linalg.eigvalsh(G)[::-1]
+        scale = np.abs(w).max()
+        assert not d[b, :off].any() and not e[b, :off].any()                    # the skipped steps
+        dr, er = sytd2_lower(G)
+        np.testing.assert_allclose(d[b, off:], dr, rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(e[b, off:255], er[: n - 1], rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(lam[b, :ell], w[:ell], rtol=0, atol=1e-13 * scale)
+        assert done[b] == 1, (b, res[b, :ell].max())
+        cols = out[b].T                                                            # (n, n): column c
+        nvec = min(n, 32 * ((ell + 31) // 32))
+        nrm = np.linalg.norm(cols[:, :nvec], axis=0)
+        np.testing.assert_allclose(nrm, np.maximum(w[:nvec], 0), rtol=0, atol=1e-12 * scale)
+        assert not cols[:, nvec:].any()
+        sig = (w[:ell] - w[ell - 1]) > 1e-10 * w[0]
+        V = cols[:, :ell][:, sig] / nrm[:ell][sig]
+        assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-9
+        assert np.abs(G @ V - V * w[:ell][sig]).max() < 1e-11 * scale
+
+
+def test_direct_solver_certifies_every_needed_pair_when_asked():
+    """cert_all (the eigenstep's use: all n_components pairs feed the embedding): a multiple eigenvalue AT the cut -- which
+    the FD certificate ignores, nothing survives the shrink there -- must send the matrix to the Jacobi."""
+    rng = np.random.default_rng(11)
+    n, need = 138, 128
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    w = np.r_[np.linspace(9.0, 2.0, 125), np.full(6, 1.5), np.linspace(1.0, 0.1, 7)]   # lam_125 .. lam_130 equal
+    G = (Q * w) @ Q.T
+    G = 0.5 * (G + G.T)
+    good = (Q * np.linspace(9.0, 0.5, n)) @ Q.T
+    good = 0.5 * (good + good.T)
+    out, d, e, lam, res, done = run_trd_n([G, good], n, need, cert_all=1)
+    assert done[0] == 0 and np.array_equal(out[0], G)          # rejected, untouched
+    assert done[1] == 1
+    ww = np.linalg.eigvalsh(good)[::-1]
+    V = out[1].T[:, :need] / np.linalg.norm(out[1].T[:, :need], axis=0)
+    assert np.abs(V.T @ V - np.eye(need)).max() < 1e-9
+    assert np.abs(good @ V - V * ww[:need]).max() < 1e-11 * ww[0]
+    # the FD certificate accepts the first matrix: the repeated eigenvalue sits at the cut, where the shrink leaves nothing
+    _, _, _, _, _, done_fd = run_trd_n([G], n, need, cert_all=0)
+    assert done_fd[0] == 1

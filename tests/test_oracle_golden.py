@@ -47,6 +47,27 @@ def test_mid_window_matches_reference():
     _check_window(g, 0, mods, labels, W, ell, k, seed)
 
 
+@pytest.mark.slow
+def test_reference_default_parameters_window_and_stream():
+    """The reference's own operating point (/root/reference/main.py:305-313: window_size 2000, reduced_dim 50, k_basis 50):
+    one window record and ten windows of its window loop (sSVDMC), oracle == reference."""
+    from mused_amd import synth
+
+    g = load_golden("refdef_blob_s0")
+    mods, labels, (n, d, W, ell, k, seed) = regen_inputs(g)
+    assert (W, ell, k) == (2000, 50, 50)
+    _check_window(g, 0, mods, labels, W, ell, k, seed)
+    g = load_golden("bench_refdef_blob_s0")
+    n_windows, W, d, ell, k, seed = (int(x) for x in g["meta"])
+    n_windows = 4   # (a prefix of the chain is a valid golden: stored per window)
+    wins = [synth.stream_window("blob", t, W, d, seed) for t in range(n_windows)]
+    assert [synth.array_digest(w[0]) for w in wins] == [str(x) for x in g["window_digest"][:n_windows]]
+    X = np.concatenate([w[0] for w in wins]).astype(np.float64)
+    labels = np.concatenate([w[1] for w in wins])
+    out = mo.process_streaming_data([X], [""], W, ell, k, seed, "sSVDMC", labels)
+    assert np.array_equal(np.asarray(out, dtype=np.int64).reshape(n_windows, W), g["labels"][:n_windows].astype(np.int64))
+
+
 @pytest.mark.parametrize(
     "name", ["c1_stream_blob_s0", "c1_stream_blob_s1", "c1_stream_gauss_s0", "c4s_stream_twomod_s0"]
 )
