@@ -106,7 +106,10 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
   const double sq = S[A_SQ] + S[A_SQ + 1];
   const double x0 = xs[k + 1];
   double tau = 0.0, beta = x0, scale = 0.0;
-  if (sq > 0.0) {
+  // (a sum of squares in the denormal range -- the rounding residue of an exactly rank-deficient matrix can deflate level by
+  // level down to there: every row the same -- is a zero column: rsq / rcp have no Newton step that survives it.  LAPACK's
+  // dlarfg rescales instead; entries below 1e-140 are nothing a Gram matrix of this path resolves.)
+  if (sq > 1e-280) {
     const double h = fma(x0, x0, sq);
     double rs = __builtin_amdgcn_rsq(h);  // 1 / sqrt(h): seed + two Newton steps
     rs = rs * fma(-0.5 * h, rs * rs, 1.5);
@@ -641,6 +644,8 @@ __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep,
     xch[cl * 4 + role] = ss;
   }
   __syncthreads();
+  if (cq == 0 && t == 0 && !(fabs(lam0) <= 1.7976931348623157e308 && tnorm <= 1.7976931348623157e308))
+    atomicOr(reinterpret_cast<int*>(wsm + W_MI + 2), 1);  // non-finite T or spectrum: nothing below can be trusted
   if (act && role == 0) {
     const double ss = 1.0 + xch[cl * 4] + xch[cl * 4 + 1];
     const double zs = 1.0 / sqrt(ss);

@@ -112,6 +112,10 @@ def test_queue_solver_timeout_raises_instead_of_returning_garbage(monkeypatch):
     rng = np.random.default_rng(0)
     monkeypatch.setenv("MUSED_EIG_QUEUE_TIMEOUT_TICKS", "1")
     monkeypatch.setenv("MUSED_EIG_QUEUE", "1")
+    # (round 4: these orders run the direct solver, whose queue Jacobi only sees rejected matrices -- switch it off so that
+    # the queue has work to give up on)
+    monkeypatch.setenv("MUSED_EIG_TRD", "0")
+    monkeypatch.setenv("MUSED_RSVD_EIG_TRD", "0")
     sk = SeqBasedSWFD(N=600, R=64.0, d=96, sketch_dim=32)
     sk.fit(rng.standard_normal((300, 96)))
     with pytest.raises(MusedError, match="gave up"):
@@ -125,6 +129,8 @@ def test_queue_solver_timeout_raises_instead_of_returning_garbage(monkeypatch):
     eng.close()
     monkeypatch.delenv("MUSED_EIG_QUEUE_TIMEOUT_TICKS")
     monkeypatch.delenv("MUSED_EIG_QUEUE")
+    monkeypatch.delenv("MUSED_EIG_TRD")
+    monkeypatch.delenv("MUSED_RSVD_EIG_TRD")
     sk = SeqBasedSWFD(N=600, R=64.0, d=96, sketch_dim=32)   # and without the knob the same calls are clean
     sk.fit(rng.standard_normal((300, 96)))
     assert sk.get()[0].shape == (32, 96)

@@ -263,3 +263,27 @@ def test_direct_solver_certifies_every_needed_pair_when_asked():
     # the FD certificate accepts the first matrix: the repeated eigenvalue sits at the cut, where the shrink leaves nothing
     _, _, _, _, _, done_fd = run_trd_n([G], n, need, cert_all=0)
     assert done_fd[0] == 1
+
+
+@pytest.mark.parametrize("n", [46, 92, 256])
+def test_direct_solver_exactly_rank_deficient_duplicates(n):
+    """Every row of the buffer the same (rank one, exact duplicates; the fuzz sweep's "const" streams): the rounding residue of
+    the trailing matrix deflates level by level into the denormal range, where a Householder step has no valid scalars
+    (round 4: NaN eigenvalues slipped through the certificate).  Such columns are now zero columns, and a non-finite T or
+    spectrum is rejected."""
+    rng = np.random.default_rng(0)
+    Gs = []
+    for rows in (n // 2, n // 2 - 3, n):
+        buf = np.zeros((n, 30))
+        buf[:rows] = rng.standard_normal(30)
+        Gs.append(buf @ buf.T)
+    out, d, e, lam, res, done = run_trd_n(Gs, n, n // 2 if n < 256 else 128)
+    for b, G in enumerate(Gs):
+        w = np.linalg.eigvalsh(G)[::-1]
+        assert np.isfinite(lam[b, : min(n // 2, 128)]).all()
+        np.testing.assert_allclose(lam[b, :4], w[:4], rtol=0, atol=1e-12 * w[0])
+        assert done[b] == 1
+        col0 = out[b][0]
+        np.testing.assert_allclose(np.linalg.norm(col0), w[0], rtol=1e-12)
+        v = col0 / np.linalg.norm(col0)
+        assert np.abs(G @ v - w[0] * v).max() < 1e-11 * w[0]
