@@ -42,8 +42,12 @@ struct EigPlan {
   unsigned* q;        // unit ring: 0 = empty, else 1 + ((matrix * 256 + global round) * 4 + block pair)
   unsigned qcap;
   struct OsjqCtl* qctl;
-  // direct solver for orders <= 256 / the leading pairs only (trd.hip): runs first, the queue Jacobi then takes the matrices it rejected
+  // direct solver for the leading pairs only: runs first, the Jacobi then takes the matrices it rejected.
+  // 1: orders <= 256 (trd.hip; fallback = the persistent queue Jacobi); 2: orders 320 .. 512 (trdx.hip; fallback = the sweep graph)
   int trd;
+  const int* jrep;     // what the Jacobi's launch-per-round kernels test (matrix b runs when jrep[b] == b): rep, or -- behind the
+                       // direct solver of orders 320 .. 512 (trdx.hip) -- the per-solve list of the matrices it rejected
+  int *trdx_act, *trdx_jrep;  // trdx: matrices that passed (act[b] == b) / that the Jacobi must solve (jrep[b] == b)
   int trd_need;        // leading eigenpairs the caller reads
   int trd_cert_all;    // every one of them must pass the certificate (eigenstep) / those that survive the FD shrink
   double* trd_ws;
@@ -927,10 +931,10 @@ static void osjw_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   const int so = sweep >= p->sort_from ? 1 : 0;
   const int rps = p->rps;  // nb - 1
   hipLaunchKernelGGL((osjw_kernel<RP, 8, true>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb, 0,
-                     p->notconv, sweep * rps, rps, p->trace, so, p->rep);
+                     p->notconv, sweep * rps, rps, p->trace, so, p->jrep);
   for (int round = 1; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, 8, false>), dim3(nb / 2, p->batch), dim3(256), 0, st, p->Gc, p->ldn, nb,
-                       round, p->notconv, sweep * rps + round, rps, p->trace, so, p->rep);
+                       round, p->notconv, sweep * rps + round, rps, p->trace, so, p->jrep);
 }
 
 // G (batch x n x n, symmetric, row-major == column-major) -> Gc (batch x ldn x ldn), zero padded
@@ -1008,11 +1012,11 @@ static void osjw4_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB;
   const int rps = p->rps;  // nb: the intra-block launch + nb - 1 block-pair rounds
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep * rps, rps, p->trace, p->sortcols, p->rep);
+                     2 * nb, 0, p->notconv, sweep * rps, rps, p->trace, p->sortcols, p->jrep);
   const int so = sweep >= p->sort_from ? 1 : 0;
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osjw_kernel<RP, 4, false>), dim3(nb / 2, p->batch), dim3(512), 0, st, p->Gc, p->ldn, nb, round,
-                       p->notconv, sweep * rps + 1 + round, rps, p->trace, so, p->rep);
+                       p->notconv, sweep * rps + 1 + round, rps, p->trace, so, p->jrep);
 }
 
 template <int NT>
@@ -1026,10 +1030,10 @@ static void osj_launch_sweep(EigPlan* p, int sweep, hipStream_t st) {
   // block -> 2*(CB/2) = CB columns per workgroup = exactly one block.
   const int rps = p->rps;  // nb
   hipLaunchKernelGGL((osj_round_kernel<OSJ_CB / 2, NT, 2>), dim3(nb, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                     2 * nb, 0, p->notconv, sweep * rps, rps, p->trace, p->sortcols, p->rep);
+                     2 * nb, 0, p->notconv, sweep * rps, rps, p->trace, p->sortcols, p->jrep);
   for (int round = 0; round < nb - 1; ++round)
     hipLaunchKernelGGL((osj_round_kernel<OSJ_CB, NT, 1>), dim3(nb / 2, p->batch), dim3(NT), 0, st, p->Gc, p->n, p->ldn,
-                       nb, round, p->notconv, sweep * rps + 1 + round, rps, p->trace, p->sortcols, p->rep);
+                       nb, round, p->notconv, sweep * rps + 1 + round, rps, p->trace, p->sortcols, p->jrep);
 }
 
 static int osj_enqueue_sweeps(EigPlan* p, hipStream_t st) {
@@ -1091,6 +1095,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
   memset(p, 0, sizeof(*p));
   p->n = n; p->batch = batch; p->sweeps = sweeps;
   p->rep = rep;
+  p->jrep = rep;
   p->err_out = err_out;
   p->method = 1;
   const size_t bytes = sizeof(double) * (size_t)batch * n * n;
@@ -1149,6 +1154,17 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         if (rc_t) return rc_t;
         MUSED_CHECK_HIP(hipMalloc(&p->trd_ws, sizeof(double) * trd_workspace_doubles(batch)));
         MUSED_CHECK_HIP(hipMalloc(&p->trd_done, sizeof(int) * (size_t)batch));
+      } else if (p->trd_need > 0 && p->wavek && trdx_supports(p->ldn, p->trd_need) &&
+                 !(getenv("MUSED_EIG_TRD") && getenv("MUSED_EIG_TRD")[0] == '0')) {
+        // orders 320 .. 512: blocked direct solver; the sweep graph below runs on the matrices it rejects (jrep)
+        p->trd = 2;
+        int rc_t = trdx_prepare(p->ldn);
+        if (rc_t) return rc_t;
+        MUSED_CHECK_HIP(hipMalloc(&p->trd_ws, sizeof(double) * trdx_workspace_doubles(p->ldn, batch)));
+        MUSED_CHECK_HIP(hipMalloc(&p->trd_done, sizeof(int) * (size_t)batch));
+        MUSED_CHECK_HIP(hipMalloc(&p->trdx_act, sizeof(int) * (size_t)batch));
+        MUSED_CHECK_HIP(hipMalloc(&p->trdx_jrep, sizeof(int) * (size_t)batch));
+        p->jrep = p->trdx_jrep;
       }
     }
     // Adaptive sweep count (default; MUSED_EIG_ADAPTIVE=0: always `sweeps` sweeps): `sweeps` is the cap, a matrix
@@ -1206,6 +1222,8 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->qclean) (void)hipFree(p->qclean);
   if (p->trd_ws) (void)hipFree(p->trd_ws);
   if (p->trd_done) (void)hipFree(p->trd_done);
+  if (p->trdx_act) (void)hipFree(p->trdx_act);
+  if (p->trdx_jrep) (void)hipFree(p->trdx_jrep);
   if (p->ev0) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
@@ -1328,8 +1346,13 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->trd) {
-      const int rc = trd_solve(p->Gc, p->n, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done, p->trd_ws,
-                               st, nullptr, rec ? p->work : nullptr, (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr);
+      const int rc = p->trd == 2
+                         ? trdx_solve(p->Gc, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done, p->trdx_act,
+                                      p->trdx_jrep, p->trd_ws, st, rec ? p->work : nullptr,
+                                      (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr)
+                         : trd_solve(p->Gc, p->n, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done,
+                                     p->trd_ws, st, nullptr, rec ? p->work : nullptr,
+                                     (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr);
       if (rc) return rc;
       if (rec) {  // the events of a direct-solver plan bracket the direct solver alone (the Jacobi behind it only sees rejects)
         MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));

@@ -28,6 +28,9 @@ int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, cons
              long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha,
              hipStream_t stream, const int* rep = nullptr);
 // rep (device, batch ints, optional): entry z is computed only when rep[z] == z (duplicates are skipped)
+int gemm_f64_acc(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb, long strideB,
+                 double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha, hipStream_t stream,
+                 const int* rep = nullptr);  // C[z] += alpha * opA(A[z]) * opB(B[z])
 
 // Sets the dynamic-LDS attribute of every plain GEMM instantiation (call before stream capture).
 int gemm_f64_prepare_all();
@@ -95,5 +98,12 @@ int trd_prepare();
 bool trd_supports(int n, int ldn, int need);
 int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
               hipStream_t st, long long* dbg_clk = nullptr, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr);
+
+// trdx.hip: blocked direct solver for padded orders 320, 384, 448, 512 (need rounded up to 32 <= order / 2)
+bool trdx_supports(int ldn, int need);
+size_t trdx_workspace_doubles(int ldn, int batch);
+int trdx_prepare(int ldn);
+int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
+               double* ws, hipStream_t st, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr);
 
 }  // namespace mused

@@ -20,44 +20,19 @@
 // lower block triangle, 72 doubles per thread, so the active trailing matrix shrinks evenly over the threads.  The diagonal
 // blocks (a == b) hold BOTH triangles at HALF weight: then  y = A v  is  y_i = sum_j H_ij v_j (row part) + sum_i H_ij v_i
 // (column part) with one uniform expression for every stored element, and the rank-2 update needs no masks either.
-#include <math.h>
 #include <stdlib.h>
 
-#include "internal.h"
-#include "wave_ops.h"
+#include "trd_common.h"
 
 namespace mused {
 
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int TN = 256, TM = 128, TNT = 512;
-// Certificate levels.  A significant vector must have a twisted-factorisation residual |(T - lam I) z| / (|z| |T|) <= TRD_RES_MAX
-// (measured: ~1e-16), a cosine <= TRD_COS_MAX with each of its 4 neighbours in the spectrum, and no 6 significant eigenvalues
-// may lie within max(1e-7 lam_0, TRD_GAP_PER_RES rmax |T|) (rmax = largest residual of the matrix): pairs 5 or more apart are
-// then separated by more than that width, which bounds their mutual contamination 2 rmax |T| / gap by 1e-8 -- the level the
-// neighbours are tested at and the parity tests assert (1e-8 sigma_1).
-constexpr double TRD_RES_MAX = 1e-13, TRD_COS_MAX = 1e-8, TRD_GAP_PER_RES = 2e8;
 // LDS map (doubles): persistent part, then a scratch region reused by the phases
 constexpr int L_D = 0, L_E = 256, L_LAM = 1024, L_ZS = 1152, L_TAU = 1280, L_MISC = 1536, L_S = 1728;
 // phase A scratch
 constexpr int A_XS = 0 /* [256] */, A_VS = 256, A_WS = 512, A_RP = 768 /* [4][256] */, A_CP = 1792 /* [2][256] */, A_RED = 2304 /* [8] */, A_SQ = 2312 /* [2] */;
 
 __host__ __device__ constexpr int tidx(int a, int b) { return a * (a + 1) / 2 + b; }
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's GLOBAL stores (s_waitcnt
-// vmcnt(0)): inside the step loops that would put the latency of a store nobody reads before a later phase (the
-// Householder vectors, the tridiagonal eigenvectors) -- or of a prefetch -- in front of every barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ double trd_rcp(double y) {  // reciprocal to rounding: hardware seed (~5e-8) + two Newton steps
-  double r = __builtin_amdgcn_rcp(y);
-  r = fma(fma(-y, r, 1.0), r, r);
-  r = fma(fma(-y, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ double trd_rcp1(double y) {  // one Newton step: ~3e-15 relative (Sturm counts: a backward error of
-  double r = __builtin_amdgcn_rcp(y);                   // that size in the off-diagonal entries, below the reduction's own)
-  return fma(fma(-y, r, 1.0), r, r);
-}
 
 // ---- phase A: one Householder step (column k), K = k / 32 selects which register blocks are still active -------------------
 // Four workgroup barriers per step: column k -> LDS | Householder vector v -> LDS | partial sums of y = A v (and of v . y)
@@ -257,94 +232,19 @@ __device__ __forceinline__ void trd_step(double (&A)[2][36], const int k, double
   TRD_TICK(5);
 }
 
-// Number of eigenvalues of T below x without a division: the sign changes of the leading principal minors
-//   p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},   p_{-1} = 1, p_0 = d_0 - x
-// (p_i / p_{i-1} is the pivot q_i of the LDL^T of T - x I: a sign change is a negative pivot; the dependent chain per row is
-// ONE fma instead of a reciprocal, its Newton step and an fma).  dd2[i] = {d_i, e_{i-1}^2} of T SCALED by a power of two to
-// |T| in [1/2, 1) with e^2 floored at 2^-120 (an absolute perturbation of 2^-60 |T| of an off-diagonal entry, far below the
-// reduction's own error): then |d_i - x| <= 2 and e^2 <= 1, a minor grows by at most 3 x per row, a pair of consecutive
-// minors shrinks by at most 2^-120 per two rows from the floor (both never vanish: e^2 > 0) and 2^-53 per row from
-// cancellation, and rescaling the pair by the power of two of its larger member every 8 rows keeps it within 2^(+-910) of 1.  An exact zero minor counts once with its successor (whose
-// sign is then -sign of its predecessor): the same count as LAPACK's "zero pivot = negative pivot".  The sign changes go
-// through a shift register of sign bits (one v_alignbit per row) that is emptied by a population count every 24 rows.
-__device__ __forceinline__ int trd_sturm(const double2* __restrict__ dd2, double x) {
-  double p0 = 1.0, p1 = dd2[0].x - x;
-  unsigned bits = (unsigned)__double2hiint(p1) >> 31;  // shift register of the minors' sign bits, newest in bit 0
-  int cnt = (int)bits;                                  // (p_{-1} = 1 > 0)
-  auto row = [&](const double2 de) {
-    const double p2 = fma(de.x - x, p1, -(de.y * p0));
-    bits = __builtin_amdgcn_alignbit(bits, (unsigned)__double2hiint(p2), 31);  // (bits << 1) | sign(p2)
-    p0 = p1;
-    p1 = p2;
-  };
-  auto rescale = [&]() {  // both minors times 2^(1023 - larger biased exponent): integer field arithmetic + two multiplications
-    const unsigned e1 = __builtin_amdgcn_ubfe((unsigned)__double2hiint(p1), 20, 11), e0 = __builtin_amdgcn_ubfe((unsigned)__double2hiint(p0), 20, 11);
-    const double f = __hiloint2double((int)((2046u - max(e1, e0)) << 20), 0);  // (a zero minor has field 0: the other one decides)
-    p1 *= f;
-    p0 *= f;
-  };
-  auto flush = [&](unsigned mask) {  // sign changes among the rows shifted in since the last flush (bit 0 stays as "previous sign")
-    cnt += __builtin_popcount((bits ^ (bits >> 1)) & mask);
-    bits &= 1u;
-  };
-  // rows 1 .. 248 in 31 blocks of 8 (one rescale each), the next block's entries loaded before the current block's chain
-  // (dd2 has 8 spare entries behind row 255), then rows 249 .. 255
-  double2 cur[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) cur[j] = dd2[1 + j];
-#pragma unroll 3
-  for (int b = 0; b < 30; ++b) {
-    double2 nxt[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nxt[j] = dd2[9 + 8 * b + j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) row(cur[j]);
-    rescale();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
-    if (b % 3 == 2) flush(0x00ffffffu);  // 24 rows: bits 0 .. 23 against bits 1 .. 24
-  }
-  {
-    double2 nxt[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nxt[j] = dd2[249 + j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) row(cur[j]);  // rows 241 .. 248
-    rescale();
-#pragma unroll
-    for (int j = 0; j < 7; ++j) row(nxt[j]);  // rows 249 .. 255
-  }
-  flush(0x00007fffu);  // 15 rows
-  return cnt;
-}
-
 // ---- workspace per matrix (doubles) --------------------------------------------------------------------------------
-constexpr long W_HS = 0;                        // 256 x 256 Householder vectors (row k = v_k)
-constexpr long W_ZG = W_HS + (long)TN * TN;     // 256 x 128 eigenvectors of T, unnormalised ([i][c])
-constexpr long W_TG = W_ZG + (long)TN * TM;     // d[256], e[256], tau[256]
-constexpr long W_LG = W_TG + 3 * TN;            // lam[128], 1 / |z| [128], residual / |T| [128]
-constexpr long W_MI = W_LG + 3 * TM;            // {|T|, pivmin, bad flag (int), ...}
-constexpr long W_TM = W_MI + 16;                // 16 blocks x (16 x 16) triangular factors of the blocked reflectors
-constexpr long W_PER = W_TM + 16 * 256;
-
-// Shape of a solve.  Orders n < 256 are EMBEDDED at the bottom right of the 256-layout (rows / columns [off, 256), off =
-// 256 - n): the first `off` Householder steps are identities and are skipped, and the steps that run start with the register
-// blocks above / left of the matrix already inactive (K = k / 32) -- an order-n solve costs what the last n columns of an
-// order-256 solve cost.  T then has `off` leading zero rows (decoupled zero eigenvalues: the Gram matrices here are PSD).
-struct TrdShape {
-  int n, ldn, off;  // order, leading dimension of the matrices in Gc (column-major, n <= ldn <= 256), 256 - n
-  int nvec;         // eigenpairs formed: a multiple of 32, <= 128
-  int need;         // the caller reads the `need` largest pairs (<= nvec)
-  int cert_all;     // 1: every pair below `need` with lam > 1e-24 lam_0 is certified (the eigenstep uses all of them);
-                    // 0: the pairs whose energy survives the FD shrink by lam_{need-1} (discard level 1e-10 lam_0)
+struct L256 {
+  static constexpr int TNX = TN, TMX = TM;
+  static constexpr long W_HS = 0;                        // 256 x 256 Householder vectors (row k = v_k)
+  static constexpr long W_ZG = W_HS + (long)TN * TN;     // 256 x 128 eigenvectors of T, unnormalised ([i][c])
+  static constexpr long W_TG = W_ZG + (long)TN * TM;     // d[256], e[256], tau[256]
+  static constexpr long W_LG = W_TG + 3 * TN;            // lam[128], 1 / |z| [128], residual / |T| [128]
+  static constexpr long W_MI = W_LG + 3 * TM;            // {|T|, pivmin, bad flag (int), ...}
+  static constexpr long W_TM = W_MI + 16;                // 16 blocks x (16 x 16) triangular factors of the blocked reflectors
+  static constexpr long W_PER = W_TM + 16 * 256;
 };
-
-// Which of the computed pairs the certificate covers (kernels C and D agree on this).
-__device__ __forceinline__ bool trd_significant(double lc, int c, double lam0, double lamcut, const TrdShape& sh) {
-  if (c >= sh.need || !(lc > 0.0)) return false;
-  const double l0 = lam0 > 0.0 ? lam0 : 0.0;
-  return sh.cert_all ? (lc > 1e-24 * l0) : ((lc - lamcut) > 1e-10 * l0);
-}
+constexpr long W_HS = L256::W_HS, W_ZG = L256::W_ZG, W_TG = L256::W_TG, W_LG = L256::W_LG, W_MI = L256::W_MI, W_TM = L256::W_TM,
+               W_PER = L256::W_PER;
 
 struct TrdDebug {
   long long* clk;            // TRD_STEP_PROFILE: batch x 16, cycles per part of a phase-A step in [8 .. 13]
@@ -419,241 +319,6 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
     wsm[W_TG + t] = sm[L_D + t];
     wsm[W_TG + TN + t] = sm[L_E + t];
     wsm[W_TG + 2 * TN + t] = sm[L_TAU + t];
-  }
-}
-
-// ================= kernel B: the TM largest eigenvalues of T, NTB / 4 per workgroup (512 / NTB workgroups per matrix) =========
-// Sturm counts at 512 equispaced points first (9 bits for every eigenvalue), then 19 passes of 5-section by the 4 lanes of a
-// quad (2.32 bits each).  NTB = 512: one workgroup per matrix, two waves per SIMD (full vector-ALU rate: large batches);
-// NTB = 128: four workgroups per matrix (small batches spread over the CUs they would leave idle; each evaluates all 512
-// points itself).  Both variants evaluate the same points in the same arithmetic: the eigenvalues do not depend on the
-// batch size (lock-step lanes == single sketches bit for bit).
-template <int NTB>
-__global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
-  constexpr int NWV = NTB / 64;
-  const int NCH = NTB == TNT ? 1 : sh.nvec / (NTB / 4);  // workgroups per matrix (NTB / 4 eigenvalues each)
-  constexpr int PASSES = 19, NPT = 512;  // 5^19 x 513 > 2^53
-  __shared__ __attribute__((aligned(16))) double2 dd2[TN + 8];
-  __shared__ double part[3 * NWV];
-  __shared__ double scal[4];
-  __shared__ int cnts[NPT];
-  const int bm = blockIdx.x / NCH, cq = blockIdx.x % NCH;
-  if (rep && rep[bm] != bm) return;
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  double* wsm = ws + (long)bm * W_PER;
-  const double* dg = wsm + W_TG;
-  const double* eg = wsm + W_TG + TN;
-  double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308, e2m = 0.0;
-  for (int i = t; i < TN; i += NTB) {
-    const double di = dg[i], em = i > 0 ? eg[i - 1] : 0.0, ep = eg[i];
-    const double rad = fabs(em) + fabs(ep);
-    lo = fmin(lo, di - rad);
-    hi = fmax(hi, di + rad);
-    e2m = fmax(e2m, ep * ep);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    lo = fmin(lo, __shfl_xor(lo, o));
-    hi = fmax(hi, __shfl_xor(hi, o));
-    e2m = fmax(e2m, __shfl_xor(e2m, o));
-  }
-  if (l == 0) { part[3 * w] = lo; part[3 * w + 1] = hi; part[3 * w + 2] = e2m; }
-  __syncthreads();
-  if (t == 0) {
-    for (int ww = 1; ww < NWV; ++ww) { lo = fmin(lo, part[3 * ww]); hi = fmax(hi, part[3 * ww + 1]); e2m = fmax(e2m, part[3 * ww + 2]); }
-    const double tn = fmax(fabs(lo), fabs(hi));
-    const double piv = 2.2250738585072014e-308 * fmax(1.0, e2m);
-    // power-of-two scale that brings |T| (Gershgorin) into [1/2, 1): exact, the eigenvalues are scaled back at the end
-    int ks = (tn > 0.0 && tn < 1.7976931348623157e308) ? __builtin_amdgcn_frexp_exp(tn) : 0;
-    ks = ks > 1000 ? 1000 : (ks < -1000 ? -1000 : ks);  // (both 2^ks and 2^-ks stay finite)
-    const double sc = __builtin_amdgcn_ldexp(1.0, -ks);
-    scal[0] = (lo - 2.0 * tn * 2.220446049250313e-16 * TN - 2.0 * piv) * sc;
-    scal[1] = (hi + 2.0 * tn * 2.220446049250313e-16 * TN + 2.0 * piv) * sc;
-    scal[2] = sc;
-    scal[3] = __builtin_amdgcn_ldexp(1.0, ks);
-    if (cq == 0) {
-      wsm[W_MI] = tn;
-      wsm[W_MI + 1] = piv;
-      reinterpret_cast<int*>(wsm + W_MI + 2)[0] = 0;  // bad flag (kernel C raises it)
-    }
-  }
-  __syncthreads();
-  const double gl = scal[0], gu = scal[1], sc = scal[2], unsc = scal[3];
-  for (int i = t; i < TN; i += NTB) {
-    const double es_ = (i > 0 ? eg[i - 1] : 0.0) * sc;
-    dd2[i] = make_double2(dg[i] * sc, fmax(es_ * es_, 7.52316384526264e-37));  // 2^-120
-  }
-  if (t < 8) dd2[TN + t] = make_double2(0.0, 0.0);  // (read ahead by the row loop, never used)
-  __syncthreads();
-  const double h0 = (gu - gl) * (1.0 / (double)(NPT + 1));
-  for (int i = t; i < NPT; i += NTB) cnts[i] = trd_sturm(dd2, fma(h0, (double)(i + 1), gl));
-  __syncthreads();
-  const int r = cq * (NTB / 4) + (t >> 2), s = t & 3, jidx = TN - 1 - r;  // r-th largest = ascending index jidx
-  if (r >= sh.nvec) return;  // (whole quads, and no barrier follows)
-  int first = 0;  // smallest point index whose count exceeds jidx (NPT: none) -- counts are non-decreasing
-  for (int step = NPT / 2; step > 0; step >>= 1)
-    if (first + step <= NPT && cnts[first + step - 1] <= jidx) first += step;
-  if (first < NPT && cnts[first] <= jidx) first += 1;
-  lo = first == 0 ? gl : fma(h0, (double)first, gl);
-  hi = first >= NPT ? gu : fma(h0, (double)(first + 1), gl);
-  for (int it = 0; it < PASSES; ++it) {
-    const double h = (hi - lo) * 0.2;
-    const double x = fma(h, (double)(s + 1), lo);
-    const int above = trd_sturm(dd2, x) > jidx ? 0 : 1;  // 1: the eigenvalue is >= x
-    int nf = above;
-    nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR1, 0xf, 0xf, false);
-    nf += __builtin_amdgcn_mov_dpp(nf, DPP_QUAD_XOR2, 0xf, 0xf, false);
-    const double nlo = fma(h, (double)nf, lo);
-    hi = (nf == 4) ? hi : fma(h, (double)(nf + 1), lo);
-    lo = nlo;
-  }
-  if (s == 0) wsm[W_LG + r] = 0.5 * (lo + hi) * unsc;
-}
-
-// ================= kernel C: eigenvectors of T by twisted factorisation, 32 per workgroup =================
-// Two waves: wave 0 runs the forward pivots and the part of each vector above its twist index, wave 1 the backward pivots
-// and the part below (two dependent chains of 255 divisions side by side); lane c < 32 of either wave = vector cq * 32 + c.
-// The pivot sequences of the 32 vectors stay in LDS ([i][vector], 2 x 64 KB: one workgroup per CU); every stretch of a
-// dependent chain is preceded by its batch of loads.
-__global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
-  extern __shared__ __attribute__((aligned(16))) double smc[];  // C_LDS doubles
-  double2* dd2 = reinterpret_cast<double2*>(smc);  // [TN]
-  double* es = smc + 2 * TN;                       // [TN]
-  double* xch = es + TN;                           // [32 * 4]
-  double* qp = xch + 128;                          // forward pivots [TN][32]
-  double* qm = qp + TN * 32;                       // backward pivots [TN][32]
-  const int nch = sh.nvec >> 5;  // workgroups per matrix
-  const int bm = blockIdx.x / nch, cq = blockIdx.x - bm * nch;
-  if (rep && rep[bm] != bm) return;
-  const int t = threadIdx.x, role = t >> 6, l = t & 63;
-  double* wsm = ws + (long)bm * W_PER;
-  double* Zg = wsm + W_ZG;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int i = t + 128 * h;
-    const double em = i > 0 ? wsm[W_TG + TN + i - 1] : 0.0;
-    dd2[i] = make_double2(wsm[W_TG + i], em * em);
-    es[i] = wsm[W_TG + TN + i];
-  }
-  __syncthreads();
-  const double tnorm = wsm[W_MI], pivmin = wsm[W_MI + 1];
-  const double lam0 = wsm[W_LG], lamcut = wsm[W_LG + sh.need - 1];
-  const bool act = l < 32;
-  const int cl = l & 31, c = cq * 32 + cl;  // (pivot arrays: column cl of this workgroup's 32)
-  const double lam = wsm[W_LG + c];
-  auto guard = [&](double v) -> double { return fabs(v) < pivmin ? -pivmin : v; };
-  if (act) {
-    if (role == 0) {
-      double qv = dd2[0].x - lam;
-      qp[cl] = qv;
-      for (int i0 = 1; i0 < TN; i0 += 5) {  // 255 = 51 x 5
-        double2 de[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) de[j] = dd2[i0 + j];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          qv = fma(-de[j].y, trd_rcp(guard(qv)), de[j].x - lam);
-          qp[(i0 + j) * 32 + cl] = qv;
-        }
-      }
-    } else {
-      double qv = dd2[TN - 1].x - lam;
-      qm[(TN - 1) * 32 + cl] = qv;
-      for (int i0 = TN - 2; i0 >= 0; i0 -= 5) {  // i0, i0 - 1, .. i0 - 4: 254 .. 0
-        double dx[5], e2[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          dx[j] = dd2[i0 - j].x - lam;
-          e2[j] = dd2[i0 - j + 1].y;
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          qv = fma(-e2[j], trd_rcp(guard(qv)), dx[j]);
-          qm[(i0 - j) * 32 + cl] = qv;
-        }
-      }
-    }
-  }
-  __syncthreads();  // (the other wave reads the pivots)
-  if (act) {  // gamma_i = qp_i + qm_i - (d_i - lam): each role scans one half, ties to the smaller index
-    const int i0 = role * (TN / 2);
-    double best = 1.7976931348623157e308;
-    int kt = i0;
-    for (int ib = i0; ib < i0 + TN / 2; ib += 16) {
-      double a[16], b[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        a[j] = qp[(ib + j) * 32 + cl];
-        b[j] = qm[(ib + j) * 32 + cl];
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double g = fabs((a[j] + b[j]) - (dd2[ib + j].x - lam));
-        if (g < best) { best = g; kt = ib + j; }
-      }
-    }
-    xch[cl * 4 + role] = best;
-    xch[cl * 4 + 2 + role] = (double)kt;
-  }
-  __syncthreads();
-  int kt = 0;
-  double gbest = 0.0;
-  if (act) {
-    const double b0 = xch[cl * 4], b1 = xch[cl * 4 + 1];
-    const bool up = !(b1 < b0);  // ties: the smaller index (first half)
-    gbest = up ? b0 : b1;
-    kt = (int)(up ? xch[cl * 4 + 2] : xch[cl * 4 + 3]);
-  }
-  __syncthreads();  // xch is read: it may be rewritten
-  if (act) {
-    double ss = 0.0, zc = 1.0;
-    if (role == 0) {
-      Zg[(long)kt * TM + c] = 1.0;
-      for (int ib = kt - 1; ib >= 0; ib -= 8) {
-        double qq[8], ee[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = ib - j;
-          qq[j] = i >= 0 ? qp[i * 32 + cl] : 1.0;
-          ee[j] = i >= 0 ? es[i] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
-          if (ib - j >= 0) Zg[(long)(ib - j) * TM + c] = zc;
-          ss = fma(zc, zc, ss);
-        }
-      }
-    } else {
-      for (int ib = kt + 1; ib < TN; ib += 8) {
-        double qq[8], ee[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = ib + j;
-          qq[j] = i < TN ? qm[i * 32 + cl] : 1.0;
-          ee[j] = i < TN ? es[i - 1] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          zc = -ee[j] * zc * trd_rcp(guard(qq[j]));
-          if (ib + j < TN) Zg[(long)(ib + j) * TM + c] = zc;
-          ss = fma(zc, zc, ss);
-        }
-      }
-    }
-    xch[cl * 4 + role] = ss;
-  }
-  __syncthreads();
-  if (cq == 0 && t == 0 && !(fabs(lam0) <= 1.7976931348623157e308 && tnorm <= 1.7976931348623157e308))
-    atomicOr(reinterpret_cast<int*>(wsm + W_MI + 2), 1);  // non-finite T or spectrum: nothing below can be trusted
-  if (act && role == 0) {
-    const double ss = 1.0 + xch[cl * 4] + xch[cl * 4 + 1];
-    const double zs = 1.0 / sqrt(ss);
-    wsm[W_LG + TM + c] = zs;
-    const double res = gbest * zs / (tnorm > 0.0 ? tnorm : 1.0);
-    wsm[W_LG + 2 * TM + c] = res;
-    if (trd_significant(lam, c, lam0, lamcut, sh) && !(ss < 1e300 && res <= TRD_RES_MAX))
-      atomicOr(reinterpret_cast<int*>(wsm + W_MI + 2), 1);
   }
 }
 
@@ -878,7 +543,7 @@ size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; 
 
 constexpr int L_A_TOTAL = L_S + 2314;            // kernel A: persistent part + its scratch
 constexpr int L_DM_TOTAL = L_S + DM_TOTAL;       // kernel D
-constexpr int C_LDS = 2 * TN + TN + 128 + 2 * TN * 32;       // kernel C: T, exchange, the pivot sequences of 32 vectors
+constexpr int C_LDS = trd_c_lds_doubles<L256, 32>();        // kernel C: T, exchange, the pivot sequences of 32 vectors
 
 int trd_prepare() {
   static std::once_flag once;
@@ -886,7 +551,7 @@ int trd_prepare() {
   std::call_once(once, [] {
     rc = hipFuncSetAttribute((const void*)trd_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * L_DM_TOTAL));
     if (rc == hipSuccess)
-      rc = hipFuncSetAttribute((const void*)trd_c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * C_LDS));
+      rc = hipFuncSetAttribute((const void*)trd_c_kernel<L256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * C_LDS));
   });
   MUSED_CHECK_HIP(rc);
   return MUSED_OK;
@@ -912,9 +577,9 @@ int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, co
   if (n == TN && ldn == TN) hipLaunchKernelGGL(trd_a_kernel<false>, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg, sh);
   else hipLaunchKernelGGL(trd_a_kernel<true>, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, Gc, rep, ws, dbg, sh);
   if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));  // profiling: the tridiagonalisation alone
-  if (batch <= 64) hipLaunchKernelGGL(trd_b_kernel<128>, dim3(nch * batch), dim3(128), 0, st, rep, ws, sh);
-  else hipLaunchKernelGGL(trd_b_kernel<512>, dim3(batch), dim3(512), 0, st, rep, ws, sh);
-  hipLaunchKernelGGL(trd_c_kernel, dim3(nch * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws, sh);
+  if (batch <= 64) hipLaunchKernelGGL((trd_b_kernel<128, L256>), dim3(nch * batch), dim3(128), 0, st, rep, ws, sh);
+  else hipLaunchKernelGGL((trd_b_kernel<512, L256>), dim3(batch), dim3(512), 0, st, rep, ws, sh);
+  hipLaunchKernelGGL((trd_c_kernel<L256, 32>), dim3(nch * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws, sh);
   hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(64), 0, st, rep, ws, sh);
   hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg, sh);
   MUSED_LAUNCH_CHECK();

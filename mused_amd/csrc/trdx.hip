@@ -1,0 +1,638 @@
+// Direct symmetric eigensolver for the Gram matrices of orders 320 .. 512 (round 4): the FD rotation at l = 256 (BASELINE
+// config 3: order 2 l = 512), the sketch query at l = 128 (order 3 l = 384, 4 l = 512 with rows pending).  Same chain as
+// trd.hip -- tridiagonalisation, the leading eigenvalues by multisection, their vectors by twisted factorisation,
+// back-transformation, certificate with the one-sided Jacobi (eig.hip) as fallback -- but a matrix of this order (1 - 2 MB)
+// is not register resident on one CU, and splitting it over several CUs would put a grid-wide exchange through L2 behind
+// every one of its n columns.  So ONE workgroup per matrix keeps the LAPACK dsytrd structure instead:
+//
+//   A  blocked Householder tridiagonalisation (dlatrd panels of 16 columns, lower variant).  Inside a panel the trailing
+//      matrix is NOT updated: column j is brought up to date from the panel's V / W (kept in registers, one matrix row per
+//      thread), y = A v STREAMS the lower triangle of the panel-start matrix from L2 / Infinity Cache -- symmetric: every
+//      128 x 32 tile is read once and serves the row part and the column part of the product -- and the rank-32 update
+//      A -= V W^T + W V^T of a finished panel runs on the matrix cores (v_mfma_f64_16x16x4, operands staged in LDS).
+//      Algorithmic bytes: n^3 / 6 doubles of symv reads per matrix (179 MB at n = 512): the kernel is bound by what one CU
+//      pulls from the memory system, not by flops.  All reductions have a fixed order: results do not depend on the batch.
+//   B, C  trd_common.h (the kernels of trd.hip, templated on the order).
+//   certificate, then  V = Q Z  blocked as compact-WY blocks of 64 reflectors on the batched fp64 MFMA GEMM of this
+//      library (S = V_b Z, C = T_b S, Z -= V_b^T C), triangular factors T_b by dlarft from the block Grams.
+//
+// The matrix is solved on a COPY (a rejected matrix goes to the Jacobi untouched), on its padded order ldn (zero rows /
+// columns add zero eigenvalues below the spectrum of a PSD matrix).
+#include <stdlib.h>
+
+#include "trd_common.h"
+
+namespace mused {
+
+constexpr int XNB = 16;  // panel width of the blocked tridiagonalisation
+constexpr int XRB = 64;  // reflectors per compact-WY block of the back-transformation
+
+template <int NX>
+struct LX {
+  static constexpr int TNX = NX, TMX = NX / 2, NBLK = NX / XRB;
+  static constexpr long W_A = 0;                                  // NX x NX   working copy of the matrix (column-major)
+  static constexpr long W_HS = W_A + (long)NX * NX;               // NX x NX   Householder vectors (row k = v_k)
+  static constexpr long W_ZG = W_HS + (long)NX * NX;              // NX x TMX  eigenvectors of T, unnormalised ([i][c])
+  static constexpr long W_ZB = W_ZG + (long)NX * TMX;             // NX x TMX  normalised, then back-transformed in place
+  static constexpr long W_TG = W_ZB + (long)NX * TMX;             // d, e, tau
+  static constexpr long W_LG = W_TG + 3 * NX;                     // lam, 1 / |z|, residual / |T|
+  static constexpr long W_MI = W_LG + 3 * TMX;                    // {|T|, pivmin, bad flag, ...}
+  static constexpr long W_TF = W_MI + 16;                         // NBLK x 64 x 64 triangular factors
+  static constexpr long W_GB = W_TF + (long)NBLK * XRB * XRB;     // NBLK x 64 x 64 block Grams V_b V_b^T
+  static constexpr long W_S = W_GB + (long)NBLK * XRB * XRB;      // 64 x TMX
+  static constexpr long W_C = W_S + (long)XRB * TMX;              // 64 x TMX
+  static constexpr long W_PER = W_C + (long)XRB * TMX;
+  static_assert(W_PER % 2 == 0 && NX % 64 == 0, "layout");
+};
+
+// 32 values per lane summed over the 64 lanes of a wave: on return r[0] of lane l is the wave total of value
+// idx = 16 (l >> 5 & 1) + 8 (l >> 4 & 1) + 4 (l >> 3 & 1) + 2 (l >> 2 & 1) + (l & 1); lanes that differ in bit 1 agree.
+__device__ __forceinline__ double wave_treduce32(double (&r)[32], const int l, int& idx) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) r[e] = swap32_add(r[e], r[e + 16]);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = swap16_add(r[e], r[e + 8]);
+  const bool h3 = (l & 8) != 0, h2 = (l & 4) != 0, h0 = (l & 1) != 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double keep = h3 ? r[e + 4] : r[e], send = h3 ? r[e] : r[e + 4];
+    r[e] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {  // partner 7 - (l & 7) of the 8-lane group: decided by bit 2
+    const double keep = h2 ? r[e + 2] : r[e], send = h2 ? r[e] : r[e + 2];
+    r[e] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+  }
+  {
+    const double keep = h0 ? r[1] : r[0], send = h0 ? r[0] : r[1];
+    r[0] = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send);
+  }
+  r[0] = r[0] + dpp_mov_f64<DPP_QUAD_XOR2>(r[0]);
+  idx = ((l >> 5) & 1) * 16 + ((l >> 4) & 1) * 8 + ((l >> 3) & 1) * 4 + ((l >> 2) & 1) * 2 + (l & 1);
+  return r[0];
+}
+
+// 16 values per lane: on return r[0] of lane l is the wave total of value idx = 8 b5 + 4 b4 + 2 b3 + b2 (b_i = bit i of l);
+// lanes that differ in bits 0 and 1 agree.
+__device__ __forceinline__ double wave_treduce16(double (&r)[16], const int l, int& idx) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = swap32_add(r[e], r[e + 8]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = swap16_add(r[e], r[e + 4]);
+  const bool h3 = (l & 8) != 0, h2 = (l & 4) != 0;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const double keep = h3 ? r[e + 2] : r[e], send = h3 ? r[e] : r[e + 2];
+    r[e] = keep + dpp_mov_f64<DPP_ROW_ROR8>(send);
+  }
+  {  // partner 7 - (l & 7) of the 8-lane group: decided by bit 2
+    const double keep = h2 ? r[1] : r[0], send = h2 ? r[0] : r[1];
+    r[0] = keep + dpp_mov_f64<DPP_ROW_HALF_MIRROR>(send);
+  }
+  r[0] = r[0] + dpp_mov_f64<DPP_QUAD_XOR1>(r[0]);
+  r[0] = r[0] + dpp_mov_f64<DPP_QUAD_XOR2>(r[0]);
+  idx = ((l >> 5) & 1) * 8 + ((l >> 4) & 1) * 4 + ((l >> 3) & 1) * 2 + ((l >> 2) & 1);
+  return r[0];
+}
+
+// ================= kernel A: blocked tridiagonalisation, one workgroup (NX threads: thread t <-> matrix row t) per matrix ======
+// LDS (doubles): vs[NX] | red[NW][34] | rowv[16] roww[16] misc[8] | U: ypart[NW][NX] during the column steps,
+// Vs[NX][17] Ws[NX][17] during the update of a finished panel.
+template <int NX>
+constexpr int trdx_a_lds_doubles() {
+  return NX + (NX / 64) * 34 + 40 + 2 * NX * 17;
+}
+
+template <int NX>
+__global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
+                                                    double* __restrict__ ws) {
+  using LY = LX<NX>;
+  constexpr int NW = NX / 64, NS = NX / 16, NT128 = (NX + 127) / 128;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int bm = blockIdx.x;
+  if (rep && rep[bm] != bm) return;
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  double* wsm = ws + (long)bm * LY::W_PER;
+  double* A = wsm + LY::W_A;
+  double* Hs = wsm + LY::W_HS;
+  double* vs = sm;
+  double* red = vs + NX;
+  double* rowv = red + NW * 34;
+  double* roww = rowv + 16;
+  double* misc = roww + 16;
+  double* U = misc + 8;
+  double* ypart = U + w * NX;  // this wave's partial sums of y = A v
+  {  // working copy (a rejected matrix goes to the Jacobi untouched)
+    const double* G = Gc + (long)bm * NX * NX;
+    for (int e = t; e < NX * NX / 2; e += NX)
+      reinterpret_cast<double2*>(A)[e] = reinterpret_cast<const double2*>(G)[e];
+  }
+  __syncthreads();
+  double Vr[XNB], Wr[XNB];
+#pragma unroll
+  for (int c = 0; c < XNB; ++c) { Vr[c] = 0.0; Wr[c] = 0.0; }
+  const int kq = l >> 4, li = l & 15;
+  for (int j0 = 0; j0 < NX; j0 += XNB) {
+    for (int i = 0; i < XNB; ++i) {
+      const int j = j0 + i;
+      // (S1) row j of the panel's V, W -> LDS; column j of the panel-start matrix
+      if (t == j) {
+#pragma unroll
+        for (int c = 0; c < XNB; ++c) { rowv[c] = Vr[c]; roww[c] = Wr[c]; }
+      }
+      double a = (t >= j) ? A[(long)j * NX + t] : 0.0;
+      lds_barrier();
+      // (S2) bring it up to date: a -= V W[j]^T + W V[j]^T over the panel's earlier columns
+#pragma unroll
+      for (int c = 0; c < XNB; ++c)
+        if (c < i) a = fma(-Vr[c], roww[c], fma(-Wr[c], rowv[c], a));
+      if (t == j) wsm[LY::W_TG + j] = a;  // d_j
+      {
+        double sq = (t > j + 1) ? a * a : 0.0;
+        sq = wave_allsum(sq);
+        if (l == 0) red[w] = sq;
+        if (t == j + 1) misc[0] = a;
+      }
+      lds_barrier();
+      // (S3) Householder vector (dlarfg), every thread for itself: beta = -sign(x0) |x|, tau = (beta - x0) / beta,
+      //      v = x / (x0 - beta).  (A sum of squares in the denormal range is a zero column: see trd.hip.)
+      double sqs = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) sqs += red[ww];
+      const double x0 = (j + 1 < NX) ? misc[0] : 0.0;
+      double tau = 0.0, beta = x0, scale = 0.0;
+      if (sqs > 1e-280) {
+        const double h = fma(x0, x0, sqs);
+        double rs = __builtin_amdgcn_rsq(h);
+        rs = rs * fma(-0.5 * h, rs * rs, 1.5);
+        rs = rs * fma(-0.5 * h, rs * rs, 1.5);
+        const double nrm = h * rs;
+        beta = x0 >= 0.0 ? -nrm : nrm;
+        tau = (beta - x0) * trd_rcp(beta);
+        scale = trd_rcp(x0 - beta);
+      }
+      const double v = (tau != 0.0) ? (t > j + 1 ? a * scale : (t == j + 1 ? 1.0 : 0.0)) : 0.0;
+      vs[t] = v;
+      Hs[(long)j * NX + t] = v;
+#pragma unroll
+      for (int c = 0; c < XNB; ++c) Vr[c] = (c == i) ? v : Vr[c];
+      if (t == 0) {
+        wsm[LY::W_TG + NX + j] = (j + 1 < NX) ? beta : 0.0;  // e_j
+        wsm[LY::W_TG + 2 * NX + j] = tau;
+      }
+#pragma unroll
+      for (int e = 0; e < NW; ++e) ypart[l + 64 * e] = 0.0;
+      lds_barrier();
+      if (tau == 0.0) {  // H = I (uniform: every thread computed the same scalars from the same data)
+#pragma unroll
+        for (int c = 0; c < XNB; ++c) Wr[c] = (c == i) ? 0.0 : Wr[c];
+        continue;
+      }
+      // (S4) y = A v over the lower triangle of the panel-start matrix, rows / columns > j (v is zero above).  Column
+      //      strips of 16, dealt to the waves in snake order (strip lengths fall linearly); per strip row tiles of 128
+      //      (two rows per lane, 16-byte loads: 16 KB in flight per wave); a tile adds  A_tile v_cols  to the rows' sums
+      //      and  A_tile^T v_rows  to the strip's 16 column sums (reduced over the lanes once per strip).
+      {
+        const int s0 = (j + 1) >> 4, L = NS - s0;
+        for (int rr = 0; rr * NW < L; ++rr) {
+          const int k = rr * NW + ((rr & 1) ? NW - 1 - w : w);
+          if (k >= L) continue;
+          const int c0 = 16 * (s0 + k);
+          double cacc[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) cacc[c] = 0.0;
+          for (int Ti = c0 >> 7; Ti < NT128; ++Ti) {
+            const int r0 = 128 * Ti + 2 * l;  // this lane's rows r0, r0 + 1
+            const bool rin = r0 < NX;
+            const double2 vrow = rin ? *reinterpret_cast<const double2*>(vs + r0) : make_double2(0.0, 0.0);
+            const bool diag = 128 * Ti < c0 + 16;  // the tile reaches into the upper triangle (not maintained): mask
+            double ra0 = 0.0, ra1 = 0.0;
+            const double* src = A + (long)c0 * NX + (rin ? r0 : 0);
+            double2 x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+              x[c] = rin ? *reinterpret_cast<const double2*>(src + (long)c * NX) : make_double2(0.0, 0.0);
+            if (!diag) {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const double vc = vs[c0 + c];
+                ra0 = fma(x[c].x, vc, ra0);
+                ra1 = fma(x[c].y, vc, ra1);
+                cacc[c] = fma(x[c].x, vrow.x, fma(x[c].y, vrow.y, cacc[c]));
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int col = c0 + c;
+                const double vc = vs[col];
+                // lower triangle only (the upper one is not maintained); the diagonal entry belongs to the row part
+                const double x0v = (r0 >= col) ? x[c].x : 0.0, x1v = (r0 + 1 >= col) ? x[c].y : 0.0;
+                ra0 = fma(x0v, vc, ra0);
+                ra1 = fma(x1v, vc, ra1);
+                const double c0v = (r0 > col) ? x0v : 0.0, c1v = (r0 + 1 > col) ? x1v : 0.0;
+                cacc[c] = fma(c0v, vrow.x, fma(c1v, vrow.y, cacc[c]));
+              }
+            }
+            if (rin) {
+              double2* yp = reinterpret_cast<double2*>(ypart + r0);
+              double2 y2 = *yp;
+              y2.x += ra0;
+              y2.y += ra1;
+              *yp = y2;
+            }
+          }
+          int idx;
+          const double cs = wave_treduce16(cacc, l, idx);
+          if ((l & 3) == 0) ypart[c0 + idx] += cs;
+        }
+      }
+      lds_barrier();
+      // (S5) y0 = sum of the waves' parts;  G1 = W^T v,  G2 = V^T v,  S = v . y0  reduced over the workgroup
+      double y0 = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) y0 += U[ww * NX + t];
+      {
+        double g[32];
+#pragma unroll
+        for (int c = 0; c < XNB; ++c) {
+          g[c] = Wr[c] * v;
+          g[16 + c] = Vr[c] * v;
+        }
+        int idx;
+        const double gs = wave_treduce32(g, l, idx);
+        if ((l & 2) == 0) red[w * 34 + idx] = gs;
+        const double ss = wave_allsum(v * y0);
+        if (l == 0) red[w * 34 + 32] = ss;
+      }
+      lds_barrier();
+      // (S6) y = y0 - V G1 - W G2;  w = tau y - (tau^2 / 2) (v . y) v   with  v . y = S - 2 G1 . G2
+      {
+        double y = y0, dot = 0.0, ssum = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) ssum += red[ww * 34 + 32];
+#pragma unroll
+        for (int c = 0; c < XNB; ++c) {
+          if (c < i) {
+            double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+              g1 += red[ww * 34 + c];
+              g2 += red[ww * 34 + 16 + c];
+            }
+            y = fma(-Vr[c], g1, fma(-Wr[c], g2, y));
+            dot = fma(g1, g2, dot);
+          }
+        }
+        const double vy = ssum - 2.0 * dot;
+        const double wv = (t > j) ? fma(tau, y, -0.5 * tau * tau * vy * v) : 0.0;
+#pragma unroll
+        for (int c = 0; c < XNB; ++c) Wr[c] = (c == i) ? wv : Wr[c];
+      }
+    }
+    // ---- the finished panel: A[r0:, r0:] -= V W^T + W V^T on the lower triangle, 16 x 16 tiles on the matrix cores ----
+    const int r0p = j0 + XNB;
+    lds_barrier();  // (every wave has read ypart / red of the last column)
+    double* Vs = U;
+    double* Ws = U + NX * 17;
+#pragma unroll
+    for (int c = 0; c < XNB; ++c) {
+      Vs[t * 17 + c] = Vr[c];
+      Ws[t * 17 + c] = Wr[c];
+    }
+    lds_barrier();
+    if (r0p < NX) {
+      const int Tt = (NX - r0p) / 16;
+      int cnt = 0;
+      for (int I = 0; I < Tt; ++I)
+        for (int J = 0; J <= I; ++J, ++cnt) {
+          if (cnt % NW != w) continue;
+          const int R = r0p + 16 * I, Cc = r0p + 16 * J;
+          // tile in the C / D layout with M = matrix column, N = matrix row: lane (kq, li), register r <-> row R + li,
+          // column Cc + kq + 4 r (lanes li read / write 16 consecutive rows of a column)
+          double* tp = A + (long)(Cc + kq) * NX + R + li;
+          v4f64 acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = tp[(long)4 * r * NX];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ws[(Cc + li) * 17 + 4 * s4 + kq], Vs[(R + li) * 17 + 4 * s4 + kq], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Vs[(Cc + li) * 17 + 4 * s4 + kq], Ws[(R + li) * 17 + 4 * s4 + kq], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tp[(long)4 * r * NX] = acc[r];
+        }
+    }
+    __syncthreads();  // the updated matrix is visible to the whole workgroup; U may be reused
+  }
+}
+
+// ================= certificate + normalisation: one workgroup per matrix =================
+// act[b] = b: the matrix passed (back-transformation and store run for it); -1: skipped (duplicate / frozen) or rejected.
+// done[b] as trd.hip; jrep[b] = what the Jacobi's launches test (rep[b] != b -> skip): -1 for solved matrices.
+template <typename LY>
+__global__ __launch_bounds__(256) void trdx_cert_kernel(const int* __restrict__ rep, double* __restrict__ ws,
+                                                        int* __restrict__ done, int* __restrict__ act, int* __restrict__ jrep,
+                                                        unsigned long long* __restrict__ work, const TrdShape sh) {
+  constexpr int TNX = LY::TNX, TMX = LY::TMX;
+  __shared__ double lam[TMX], zs[TMX], rs[TMX];
+  __shared__ int bad;
+  __shared__ double rmax_s;
+  const int bm = blockIdx.x, t = threadIdx.x;
+  if (rep && rep[bm] != bm) {  // (the Jacobi skips it too)
+    if (t == 0) { done[bm] = 1; act[bm] = -1; jrep[bm] = rep[bm]; }
+    return;
+  }
+  double* wsm = ws + (long)bm * LY::W_PER;
+  const double* Zg = wsm + LY::W_ZG;
+  for (int c = t; c < sh.nvec; c += 256) {
+    lam[c] = wsm[LY::W_LG + c];
+    zs[c] = wsm[LY::W_LG + TMX + c];
+    rs[c] = wsm[LY::W_LG + 2 * TMX + c];
+  }
+  if (t == 0) bad = reinterpret_cast<const int*>(wsm + LY::W_MI + 2)[0];
+  __syncthreads();
+  const double lam0 = lam[0], lamcut = lam[sh.need - 1];
+  auto significant = [&](int c) -> bool { return c < sh.nvec && trd_significant(lam[c], c, lam0, lamcut, sh); };
+  if (t == 0) {
+    double rmax = 0.0;  // largest residual among the significant vectors
+    for (int c = 0; c < sh.nvec; ++c) rmax = (significant(c) && rs[c] > rmax) ? rs[c] : rmax;
+    rmax_s = rmax;
+  }
+  __syncthreads();
+  const double width = fmax(1e-7 * lam0, TRD_GAP_PER_RES * rmax_s * wsm[LY::W_MI]);
+  for (int pr = t; pr < 4 * sh.nvec; pr += 256) {
+    const int c = pr >> 2, c2 = c + (pr & 3) + 1;
+    if (c2 < sh.nvec && significant(c) && significant(c2)) {
+      double dotv = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < TNX; ++i) dotv = fma(Zg[(long)i * TMX + c], Zg[(long)i * TMX + c2], dotv);
+      if (!(fabs(dotv) * zs[c] * zs[c2] <= TRD_COS_MAX)) atomicOr(&bad, 2);
+    }
+    if ((pr & 3) == 0 && c + 5 < sh.nvec && significant(c) && significant(c + 5) && (lam[c] - lam[c + 5]) <= width)
+      atomicOr(&bad, 4);
+  }
+  __syncthreads();
+  const bool ok = bad == 0;
+  if (t == 0) {
+    done[bm] = ok ? 1 : 0;
+    act[bm] = ok ? bm : -1;
+    jrep[bm] = ok ? -1 : bm;
+    if (ok && work) atomicAdd(work, 1ull);
+  }
+  if (!ok) return;
+  double* Zb = wsm + LY::W_ZB;
+  for (int e = t; e < TNX * sh.nvec; e += 256) {
+    const int i = e / sh.nvec, c = e - i * sh.nvec;
+    Zb[(long)i * TMX + c] = Zg[(long)i * TMX + c] * zs[c];
+  }
+}
+
+// ================= triangular factors of the blocks of 64 reflectors (LAPACK dlarft, forward / columnwise) =================
+//   H_k0 ... H_k0+63 = I - V T V^T,  T upper triangular:  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i)
+// from the block Gram  Gb = V_b V_b^T  (batched GEMM).  One workgroup (64 threads: thread = row of T) per block and matrix.
+template <typename LY>
+__global__ __launch_bounds__(64) void trdx_larft_kernel(const int* __restrict__ act, double* __restrict__ ws) {
+  constexpr int TNX = LY::TNX;
+  // G is symmetric: thread l reads G[b2][c] as Gs[c][b2] (lanes walk b2 = l + k: consecutive addresses); row l of T is kept as
+  // column l of Tt (address b2 * 64 + l: stride 65 over the lanes) -- both conflict free without padding, 2 x 32 KB
+  extern __shared__ __attribute__((aligned(16))) double lsm[];  // 2 x 64 x 64 doubles (64 KB: set as a dynamic size)
+  double (*Gs)[XRB] = reinterpret_cast<double (*)[XRB]>(lsm);
+  double (*Tt)[XRB] = reinterpret_cast<double (*)[XRB]>(lsm + XRB * XRB);
+  const int kb = blockIdx.x, bm = blockIdx.y, l = threadIdx.x;
+  if (act[bm] != bm) return;
+  double* wsm = ws + (long)bm * LY::W_PER;
+  const double* Gb = wsm + LY::W_GB + (long)kb * XRB * XRB;
+  for (int c = 0; c < XRB; ++c) {
+    Gs[c][l] = Gb[c * XRB + l];
+    Tt[c][l] = 0.0;
+  }
+  __syncthreads();
+  for (int c = 0; c < XRB; ++c) {  // column c only needs the columns before it; row l of T is this thread's
+    const double tau = wsm[LY::W_TG + 2 * TNX + XRB * kb + c];
+    double v = 0.0;
+    if (l == c) v = tau;
+    else if (l < c) {
+      double accv = 0.0;
+      for (int b2 = l; b2 < c; ++b2) accv = fma(Tt[b2][l], Gs[c][b2], accv);
+      v = -tau * accv;
+    }
+    Tt[c][l] = v;  // T[l][c]
+  }
+  __syncthreads();
+  double* Tf = wsm + LY::W_TF + (long)kb * XRB * XRB;
+  for (int r = 0; r < XRB; ++r) Tf[r * XRB + l] = Tt[l][r];  // row-major T[r][l]
+}
+
+// ================= result: column c of the matrix <- lam_c v_c (c < nvec), zeros elsewhere; 64 x 64 tiles through LDS ========
+template <typename LY>
+__global__ __launch_bounds__(256) void trdx_store_kernel(const int* __restrict__ act, const double* __restrict__ ws,
+                                                         double* __restrict__ Gc, const TrdShape sh) {
+  constexpr int TNX = LY::TNX, TMX = LY::TMX, NT = TNX / 64;
+  __shared__ double tile[64][65];
+  const int bm = blockIdx.y;
+  if (act[bm] != bm) return;
+  const int ti = blockIdx.x / NT, tc = blockIdx.x % NT;  // rows 64 ti .., columns 64 tc ..
+  const double* wsm = ws + (long)bm * LY::W_PER;
+  const double* Zb = wsm + LY::W_ZB;
+  double* G = Gc + (long)bm * TNX * TNX;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = 64 * tc + tx;
+  const double lc = c < sh.nvec ? wsm[LY::W_LG + c] : 0.0;
+  const double f = lc > 0.0 ? lc : 0.0;
+  for (int r = ty; r < 64; r += 4) tile[r][tx] = (c < sh.nvec) ? f * Zb[(long)(64 * ti + r) * TMX + c] : 0.0;
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) G[(long)(64 * tc + cc) * TNX + 64 * ti + tx] = tile[tx][cc];
+}
+
+template <typename LY>
+__global__ void trdx_export_kernel(const double* __restrict__ ws, double* __restrict__ d, double* __restrict__ e,
+                                   double* __restrict__ lam, double* __restrict__ res, int nvec) {
+  const int bm = blockIdx.x, t = threadIdx.x;
+  const double* wsm = ws + (long)bm * LY::W_PER;
+  if (d) d[(long)bm * LY::TNX + t] = wsm[LY::W_TG + t];
+  if (e) e[(long)bm * LY::TNX + t] = wsm[LY::W_TG + LY::TNX + t];
+  if (t < nvec) {
+    if (lam) lam[(long)bm * LY::TMX + t] = wsm[LY::W_LG + t];
+    if (res) res[(long)bm * LY::TMX + t] = wsm[LY::W_LG + 2 * LY::TMX + t];
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------
+template <int NX>
+static int trdx_prepare_t() {
+  using LY = LX<NX>;
+  static std::once_flag once;
+  static hipError_t rc = hipSuccess;
+  std::call_once(once, [] {
+    rc = hipFuncSetAttribute((const void*)trdx_a_kernel<NX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)(sizeof(double) * trdx_a_lds_doubles<NX>()));
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)trd_c_kernel<LY, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * trd_c_lds_doubles<LY, 16>()));
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)trdx_larft_kernel<LY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * 2 * XRB * XRB));
+  });
+  MUSED_CHECK_HIP(rc);
+  return gemm_f64_prepare_all();
+}
+
+template <int NX>
+static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* rep, int* done, int* act, int* jrep, double* ws,
+                        hipStream_t st, unsigned long long* work, hipEvent_t after_a) {
+  using LY = LX<NX>;
+  const long per = LY::W_PER;
+  const int nvec = sh.nvec, nch32 = nvec / 32, nch16 = nvec / 16;
+  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(NX), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws);
+  if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));
+  hipLaunchKernelGGL((trd_b_kernel<128, LY>), dim3(nch32 * batch), dim3(128), 0, st, rep, ws, sh);
+  constexpr size_t c_lds = sizeof(double) * trd_c_lds_doubles<LY, 16>();
+  hipLaunchKernelGGL((trd_c_kernel<LY, 16>), dim3(nch16 * batch), dim3(128), c_lds, st, rep, ws, sh);
+  hipLaunchKernelGGL(trdx_cert_kernel<LY>, dim3(batch), dim3(256), 0, st, rep, ws, done, act, jrep, work, sh);
+  MUSED_LAUNCH_CHECK();
+  int rc;
+  // block Grams and triangular factors of the compact-WY blocks
+  for (int b = 0; b < LY::NBLK; ++b) {
+    const double* Vb = ws + LY::W_HS + (long)XRB * b * NX + XRB * b;  // rows 64 b .., columns 64 b .. (zeros to the left)
+    if ((rc = gemm_f64(true, true, Vb, NX, per, Vb, NX, per, ws + LY::W_GB + (long)b * XRB * XRB, XRB, per, XRB, XRB,
+                       NX - XRB * b, batch, 1.0, st, act)))
+      return rc;
+  }
+  hipLaunchKernelGGL(trdx_larft_kernel<LY>, dim3(LY::NBLK, batch), dim3(64), sizeof(double) * 2 * XRB * XRB, st, act, ws);
+  MUSED_LAUNCH_CHECK();
+  // Z <- H_0 H_1 ... Z: blocks in reverse order, each  Z -= V_b^T (T_b (V_b Z))  on rows 64 b ..
+  for (int b = LY::NBLK - 1; b >= 0; --b) {
+    const double* Vb = ws + LY::W_HS + (long)XRB * b * NX + XRB * b;
+    double* Zb = ws + LY::W_ZB + (long)XRB * b * LY::TMX;
+    const int K = NX - XRB * b;
+    if ((rc = gemm_f64(true, false, Vb, NX, per, Zb, LY::TMX, per, ws + LY::W_S, LY::TMX, per, XRB, nvec, K, batch, 1.0, st, act)))
+      return rc;
+    if ((rc = gemm_f64(true, false, ws + LY::W_TF + (long)b * XRB * XRB, XRB, per, ws + LY::W_S, LY::TMX, per, ws + LY::W_C,
+                       LY::TMX, per, XRB, nvec, XRB, batch, 1.0, st, act)))
+      return rc;
+    if ((rc = gemm_f64_acc(false, false, Vb, NX, per, ws + LY::W_C, LY::TMX, per, Zb, LY::TMX, per, K, nvec, XRB, batch, -1.0, st,
+                           act)))
+      return rc;
+  }
+  hipLaunchKernelGGL(trdx_store_kernel<LY>, dim3((NX / 64) * (NX / 64), batch), dim3(256), 0, st, act, ws, Gc, sh);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
+bool trdx_supports(int ldn, int need) {
+  return (ldn == 320 || ldn == 384 || ldn == 448 || ldn == 512) && need >= 1 && ((need + 31) / 32) * 32 <= ldn / 2;
+}
+
+size_t trdx_workspace_doubles(int ldn, int batch) {
+  switch (ldn) {
+    case 320: return (size_t)batch * LX<320>::W_PER;
+    case 384: return (size_t)batch * LX<384>::W_PER;
+    case 448: return (size_t)batch * LX<448>::W_PER;
+    default: return (size_t)batch * LX<512>::W_PER;
+  }
+}
+
+int trdx_prepare(int ldn) {
+  switch (ldn) {
+    case 320: return trdx_prepare_t<320>();
+    case 384: return trdx_prepare_t<384>();
+    case 448: return trdx_prepare_t<448>();
+    case 512: return trdx_prepare_t<512>();
+    default: set_error("trdx_prepare: unsupported order %d", ldn); return MUSED_ERR_UNSUPPORTED;
+  }
+}
+
+// Solves the matrices of Gc (batch x ldn x ldn column-major, symmetric, zero padded beyond the caller's order) in place:
+// done[b] = 1 -> columns 0 .. nvec - 1 of matrix b hold lam_j v_j for its largest eigenvalues (descending; nvec = `need` rounded up
+// to a multiple of 32), every other entry zeros; done[b] = 0 -> untouched (certificate failed: the Jacobi solves it; jrep[b] = b).
+// act / jrep: batch ints each (device).  ws: trdx_workspace_doubles(ldn, batch).
+int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
+               double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a) {
+  MUSED_REQUIRE(trdx_supports(ldn, need), "trdx_solve: unsupported shape (order %d, need %d)", ldn, need);
+  TrdShape sh;
+  sh.n = ldn; sh.ldn = ldn; sh.off = 0;
+  sh.nvec = ((need + 31) / 32) * 32;
+  sh.need = need;
+  sh.cert_all = cert_all ? 1 : 0;
+  switch (ldn) {
+    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
+    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
+    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
+    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
+  }
+}
+
+}  // namespace mused
+
+using namespace mused;
+
+// Diagnostic / unit-test entry (not part of the declared ABI): the solver alone on `batch` symmetric matrices of order
+// n in {320, 384, 448, 512} (device, column-major, overwritten as trdx_solve does).  out_d / out_e: batch x n, out_lam / out_res:
+// batch x n / 2 (the first `need` rounded up to 32 are formed), out_done: batch ints.
+extern "C" int mused_debug_trdx(double* G, int n, int need, int cert_all, int batch, double* out_d, double* out_e,
+                                double* out_lam, double* out_res, int* out_done, void* stream) {
+  MUSED_REQUIRE(G && batch >= 1 && out_done && trdx_supports(n, need), "mused_debug_trdx: bad arguments");
+  int rc = trdx_prepare(n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  double* ws = nullptr;
+  int* ib = nullptr;
+  MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trdx_workspace_doubles(n, batch)));
+  MUSED_CHECK_HIP(hipMalloc((void**)&ib, sizeof(int) * 2 * (size_t)batch));
+  rc = trdx_solve(G, n, need, cert_all != 0, batch, nullptr, out_done, ib, ib + batch, ws, st, nullptr, nullptr);
+  if (!rc) {
+    const int nvec = ((need + 31) / 32) * 32;
+    switch (n) {
+      case 320: hipLaunchKernelGGL((trdx_export_kernel<LX<320>>), dim3(batch), dim3(320), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
+      case 384: hipLaunchKernelGGL((trdx_export_kernel<LX<384>>), dim3(batch), dim3(384), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
+      case 448: hipLaunchKernelGGL((trdx_export_kernel<LX<448>>), dim3(batch), dim3(448), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
+      default: hipLaunchKernelGGL((trdx_export_kernel<LX<512>>), dim3(batch), dim3(512), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
+    }
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(ws);
+  (void)hipFree(ib);
+  if (rc) return rc;
+  MUSED_CHECK_HIP(e);
+  return MUSED_OK;
+}
+
+// Diagnostic: average time (ms, HIP events) of `reps` solves of the same `batch` matrices (restored from a copy before every
+// solve, outside the timed region); out_a_ms: the part up to the end of the tridiagonalisation kernel.
+extern "C" int mused_debug_trdx_time(const double* G, int n, int need, int batch, int reps, double* out_ms, double* out_a_ms,
+                                     int* out_done, void* stream) {
+  MUSED_REQUIRE(G && batch >= 1 && reps >= 1 && out_ms && trdx_supports(n, need), "mused_debug_trdx_time: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = trdx_prepare(n);
+  if (rc) return rc;
+  double *ws = nullptr, *work = nullptr;
+  int* ib = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)batch * n * n;
+  MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trdx_workspace_doubles(n, batch)));
+  MUSED_CHECK_HIP(hipMalloc((void**)&work, bytes));
+  MUSED_CHECK_HIP(hipMalloc((void**)&ib, sizeof(int) * 3 * (size_t)batch));
+  hipEvent_t e0, e1, ea;
+  MUSED_CHECK_HIP(hipEventCreate(&e0));
+  MUSED_CHECK_HIP(hipEventCreate(&e1));
+  MUSED_CHECK_HIP(hipEventCreate(&ea));
+  double total = 0.0, total_a = 0.0;
+  for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
+    MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
+    MUSED_CHECK_HIP(hipEventRecord(e0, st));
+    rc = trdx_solve(work, n, need, false, batch, nullptr, ib, ib + batch, ib + 2 * batch, ws, st, nullptr, ea);
+    MUSED_CHECK_HIP(hipEventRecord(e1, st));
+    MUSED_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f, msa = 0.f;
+    MUSED_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    MUSED_CHECK_HIP(hipEventElapsedTime(&msa, e0, ea));
+    if (i > 0) { total += ms; total_a += msa; }
+  }
+  *out_ms = total / reps;
+  if (out_a_ms) *out_a_ms = total_a / reps;
+  if (out_done) MUSED_CHECK_HIP(hipMemcpy(out_done, ib, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(ea);
+  (void)hipFree(ws); (void)hipFree(work); (void)hipFree(ib);
+  return rc;
+}

@@ -287,3 +287,68 @@ def test_direct_solver_exactly_rank_deficient_duplicates(n):
         np.testing.assert_allclose(np.linalg.norm(col0), w[0], rtol=1e-12)
         v = col0 / np.linalg.norm(col0)
         assert np.abs(G @ v - w[0] * v).max() < 1e-11 * w[0]
+
+
+def run_trdx(Gs, n, need, cert_all=0):
+    """The blocked solver of orders 320 .. 512 (csrc/trdx.hip)."""
+    from mused_amd import _lib
+    from mused_amd.engine import ptr, stream_ptr
+
+    L = _lib.lib()
+    fn = L.mused_debug_trdx
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+    B = len(Gs)
+    G = torch.from_numpy(np.ascontiguousarray(np.stack(Gs))).cuda()
+    d = torch.zeros(B, n, dtype=torch.float64, device="cuda")
+    e = torch.zeros(B, n, dtype=torch.float64, device="cuda")
+    lam = torch.zeros(B, n // 2, dtype=torch.float64, device="cuda")
+    res = torch.zeros(B, n // 2, dtype=torch.float64, device="cuda")
+    done = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(fn(ptr(G), n, need, cert_all, B, ptr(d), ptr(e), ptr(lam), ptr(res), ptr(done), stream_ptr()))
+    torch.cuda.synchronize()
+    return G.cpu().numpy(), d.cpu().numpy(), e.cpu().numpy(), lam.cpu().numpy(), res.cpu().numpy(), done.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,need", [(320, 160), (384, 128), (448, 224), (512, 256), (512, 128)])
+def test_blocked_direct_solver_matches_lapack(n, need):
+    """Orders 320 .. 512 (config 3's rotations at l = 256: order 512, top 256; the sketch query at l = 128: order 384 / 512,
+    top 128): blocked tridiagonalisation (the same T as the unblocked reduction, to rounding), leading eigenpairs against
+    LAPACK, zero columns elsewhere, same certificate."""
+    ell = n // 2
+    Gs = fd_buffers("blob", 3, ell=ell, d=1024) + fd_buffers("fd", 2, ell=ell, d=700, seed=1)
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, 90))
+    Gs.append(B @ B.T)                                     # rank 90: most of the spectrum zero
+    out, d, e, lam, res, done = run_trdx(Gs, n, need)
+    nvec = 32 * ((need + 31) // 32)
+    for b, G in enumerate(Gs):
+        w = np.linalg.eigvalsh(G)[::-1]
+        scale = np.abs(w).max()
+        dr, er = sytd2_lower(G)
+        np.testing.assert_allclose(d[b], dr, rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(np.abs(e[b, : n - 1]), np.abs(er[: n - 1]), rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(lam[b, :nvec], w[:nvec], rtol=0, atol=2e-13 * scale)
+        assert done[b] == 1, (b, res[b, :need].max())
+        cols = out[b].T
+        nrm = np.linalg.norm(cols[:, :nvec], axis=0)
+        np.testing.assert_allclose(nrm, np.maximum(w[:nvec], 0), rtol=0, atol=1e-11 * scale)
+        assert not cols[:, nvec:].any()
+        sig = (w[:need] > 0) & ((w[:need] - w[need - 1]) > 1e-10 * w[0])
+        V = cols[:, :need][:, sig] / nrm[:need][sig]
+        assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-9
+        assert np.abs(G @ V - V * w[:need][sig]).max() < 1e-10 * scale
+
+
+def test_blocked_direct_solver_rejects_clusters_and_leaves_the_matrix():
+    rng = np.random.default_rng(5)
+    n = 384
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    w = np.r_[np.full(40, 7.0), np.linspace(6.0, 0.5, n - 40)]       # 40-fold eigenvalue above the cut
+    G = (Q * w) @ Q.T
+    G = 0.5 * (G + G.T)
+    out, d, e, lam, res, done = run_trdx([G, np.zeros((n, n)), np.eye(n) * 2.0], n, 128)
+    assert done[0] == 0 and np.array_equal(out[0], G)
+    np.testing.assert_allclose(lam[0, :128], np.sort(w)[::-1][:128], rtol=0, atol=1e-12 * 7.0)
+    assert done[1] == 1 and np.abs(out[1]).max() < 1e-290            # zero matrix: nothing significant
+    assert done[2] == 1                                               # identity: nothing survives the shrink
