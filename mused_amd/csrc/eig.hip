@@ -1280,6 +1280,7 @@ int eig_plan_profile_read(EigPlan* p, double* total_ms, long* launches, double* 
   double frac = 1.0;
   if (p->work && p->prof_n > 0) {
     unsigned long long w = 0;
+    CaptureLock guard(capture_mutex());  // (a blocking legacy-stream copy: not beside another thread's stream capture)
     MUSED_CHECK_HIP(hipMemcpy(&w, p->work, 8, hipMemcpyDeviceToHost));
     frac = (double)w / ((double)p->prof_n * p->sweeps * p->rps * p->batch);
   }
@@ -1304,6 +1305,7 @@ int eig_plan_profile_read_direct(EigPlan* p, double* total_ms, long* launches, d
   *launches = p->prof_n;
   if (p->work) {
     unsigned long long w = 0;
+    CaptureLock guard(capture_mutex());  // (a blocking legacy-stream copy: not beside another thread's stream capture)
     MUSED_CHECK_HIP(hipMemcpy(&w, p->work, 8, hipMemcpyDeviceToHost));
     *matrices_solved = (double)w;
   }

@@ -46,6 +46,7 @@ struct Swfd {
   int* keep_src;  // S x ell      buffer position -> row of T
   long long* now_dev;
   int* status;  // device word, sticky: bit 0 = an eigensolve of this sketch gave up (work-queue timeout): results invalid
+  int* status_host;  // pinned copy target of mused_swfd_status (asynchronous copy on the caller's stream)
   EigPlan* eig;
   // query workspace
   double *stack, *evals_q, *Uq, *Wq, *Bout, *sig_out, *qinfo;
@@ -695,6 +696,7 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
   }
   ZALLOC(h->dropped, 8 * S);
   ZALLOC(h->status, 4);
+  MUSED_CHECK_HIP(hipHostMalloc((void**)&h->status_host, sizeof(int), hipHostMallocDefault));
   ALLOC(h->theta, 8 * S);
   ALLOC(h->T, 8 * S * l * dd); ALLOC(h->Wc, 8 * S * l * n2); ALLOC(h->evals, 8 * S * n2); ALLOC(h->U, 8 * S * n2 * n2);
   ALLOC(h->plan, 4 * S * l * 2); ALLOC(h->keep_src, 4 * S * l); ALLOC(h->now_dev, 8);
@@ -755,6 +757,7 @@ int mused_swfd_destroy(void* handle) {
                   h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel,
                   h->rep, h->pre_in, h->pre_out, h->pre_gram, h->status};
   for (void* b : bufs) (void)hipFree(b);
+  if (h->status_host) (void)hipHostFree(h->status_host);
   delete h;
   return MUSED_OK;
 }
@@ -843,8 +846,11 @@ int mused_swfd_query(void* handle, double* out_sketch, double* out_sigma, double
 int mused_swfd_status(void* handle, int* status_out, void* stream) {
   Swfd* h = (Swfd*)handle;
   MUSED_REQUIRE(h && status_out, "mused_swfd_status: null pointer");
+  // an asynchronous copy on the caller's stream into pinned memory + a wait for that stream only: no legacy-stream
+  // blocking copy (device-wide synchronisation next to another thread's stream capture is what kills the capture)
+  MUSED_CHECK_HIP(hipMemcpyAsync(h->status_host, h->status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   MUSED_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  MUSED_CHECK_HIP(hipMemcpy(status_out, h->status, sizeof(int), hipMemcpyDeviceToHost));
+  *status_out = *h->status_host;
   return MUSED_OK;
 }
 

@@ -96,16 +96,16 @@ __device__ __forceinline__ double wave_treduce16(double (&r)[16], const int l, i
 }
 
 // ================= kernel A: blocked tridiagonalisation, one workgroup (NX threads: thread t <-> matrix row t) per matrix ======
-// LDS (doubles): vs[NX] | red[NW][34] | rowv[16] roww[16] misc[8] | U: ypart[NW][NX] during the column steps,
+// LDS (doubles): vs[NX] | red[NW][34] | rowv[16] roww[16] misc[8] gsum[34] | U: ypart[NW][NX] during the column steps,
 // Vs[NX][17] Ws[NX][17] during the update of a finished panel.
 template <int NX>
 constexpr int trdx_a_lds_doubles() {
-  return NX + (NX / 64) * 34 + 40 + 2 * NX * 17;
+  return NX + (NX / 64) * 34 + 40 + 34 + 2 * NX * 17;
 }
 
 template <int NX>
 __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
-                                                    double* __restrict__ ws) {
+                                                    double* __restrict__ ws, long long* __restrict__ prof) {
   using LY = LX<NX>;
   constexpr int NW = NX / 64, NS = NX / 16, NT128 = (NX + 127) / 128;
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
   double* rowv = red + NW * 34;
   double* roww = rowv + 16;
   double* misc = roww + 16;
-  double* U = misc + 8;
+  double* gsum = misc + 8;  // [34]
+  double* U = gsum + 34;
   double* ypart = U + w * NX;  // this wave's partial sums of y = A v
   {  // working copy (a rejected matrix goes to the Jacobi untouched)
     const double* G = Gc + (long)bm * NX * NX;
@@ -132,15 +133,27 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
 #pragma unroll
   for (int c = 0; c < XNB; ++c) { Vr[c] = 0.0; Wr[c] = 0.0; }
   const int kq = l >> 4, li = l & 15;
+  // diagnostic (prof != nullptr): s_memtime ticks of thread 0 in [column + Householder | symv | reductions + w | panel update]
+  long long pacc[4] = {0, 0, 0, 0}, plast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  auto ptick = [&](int slot) {
+    if (prof) {
+      const long long now = (long long)__builtin_amdgcn_s_memtime();
+      pacc[slot] += now - plast;
+      plast = now;
+    }
+  };
   for (int j0 = 0; j0 < NX; j0 += XNB) {
+    double anext = A[(long)j0 * NX + t];  // column j0 of the matrix as the last panel update left it
     for (int i = 0; i < XNB; ++i) {
       const int j = j0 + i;
-      // (S1) row j of the panel's V, W -> LDS; column j of the panel-start matrix
+      // (S1) row j of the panel's V, W -> LDS; column j of the panel-start matrix (fetched a column ahead: the matrix does
+      //      not change inside a panel, and the load's latency would otherwise sit in front of every column)
       if (t == j) {
 #pragma unroll
         for (int c = 0; c < XNB; ++c) { rowv[c] = Vr[c]; roww[c] = Wr[c]; }
       }
-      double a = (t >= j) ? A[(long)j * NX + t] : 0.0;
+      double a = (t >= j) ? anext : 0.0;
+      if (i + 1 < XNB) anext = A[(long)(j + 1) * NX + t];
       lds_barrier();
       // (S2) bring it up to date: a -= V W[j]^T + W V[j]^T over the panel's earlier columns
 #pragma unroll
@@ -183,6 +196,7 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
 #pragma unroll
       for (int e = 0; e < NW; ++e) ypart[l + 64 * e] = 0.0;
       lds_barrier();
+      ptick(0);
       if (tau == 0.0) {  // H = I (uniform: every thread computed the same scalars from the same data)
 #pragma unroll
         for (int c = 0; c < XNB; ++c) Wr[c] = (c == i) ? 0.0 : Wr[c];
@@ -247,7 +261,10 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
         }
       }
       lds_barrier();
-      // (S5) y0 = sum of the waves' parts;  G1 = W^T v,  G2 = V^T v,  S = v . y0  reduced over the workgroup
+      ptick(1);
+      // (S5) y0 = sum of the waves' parts;  G1 = W^T v,  G2 = V^T v,  S = v . y0  reduced over the workgroup: per wave by a
+      //      transposing reduction, over the waves by the first 33 threads (every thread summing the 8 x 33 partials itself
+      //      cost more LDS cycles than the barrier this takes)
       double y0 = 0.0;
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) y0 += U[ww * NX + t];
@@ -265,29 +282,30 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
         if (l == 0) red[w * 34 + 32] = ss;
       }
       lds_barrier();
+      if (t < 33) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) sacc += red[ww * 34 + t];
+        gsum[t] = sacc;
+      }
+      lds_barrier();
       // (S6) y = y0 - V G1 - W G2;  w = tau y - (tau^2 / 2) (v . y) v   with  v . y = S - 2 G1 . G2
       {
-        double y = y0, dot = 0.0, ssum = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) ssum += red[ww * 34 + 32];
+        double y = y0, dot = 0.0;
 #pragma unroll
         for (int c = 0; c < XNB; ++c) {
           if (c < i) {
-            double g1 = 0.0, g2 = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) {
-              g1 += red[ww * 34 + c];
-              g2 += red[ww * 34 + 16 + c];
-            }
+            const double g1 = gsum[c], g2 = gsum[16 + c];
             y = fma(-Vr[c], g1, fma(-Wr[c], g2, y));
             dot = fma(g1, g2, dot);
           }
         }
-        const double vy = ssum - 2.0 * dot;
+        const double vy = gsum[32] - 2.0 * dot;
         const double wv = (t > j) ? fma(tau, y, -0.5 * tau * tau * vy * v) : 0.0;
 #pragma unroll
         for (int c = 0; c < XNB; ++c) Wr[c] = (c == i) ? wv : Wr[c];
       }
+      ptick(2);
     }
     // ---- the finished panel: A[r0:, r0:] -= V W^T + W V^T on the lower triangle, 16 x 16 tiles on the matrix cores ----
     const int r0p = j0 + XNB;
@@ -323,7 +341,10 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
         }
     }
     __syncthreads();  // the updated matrix is visible to the whole workgroup; U may be reused
+    ptick(3);
   }
+  if (prof && t == 0)
+    for (int q = 0; q < 4; ++q) prof[(long)bm * 4 + q] = pacc[q];
 }
 
 // ================= certificate + normalisation: one workgroup per matrix =================
@@ -479,11 +500,11 @@ static int trdx_prepare_t() {
 
 template <int NX>
 static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* rep, int* done, int* act, int* jrep, double* ws,
-                        hipStream_t st, unsigned long long* work, hipEvent_t after_a) {
+                        hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
   using LY = LX<NX>;
   const long per = LY::W_PER;
   const int nvec = sh.nvec, nch32 = nvec / 32, nch16 = nvec / 16;
-  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(NX), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws);
+  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(NX), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws, prof);
   if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));
   hipLaunchKernelGGL((trd_b_kernel<128, LY>), dim3(nch32 * batch), dim3(128), 0, st, rep, ws, sh);
   constexpr size_t c_lds = sizeof(double) * trd_c_lds_doubles<LY, 16>();
@@ -547,7 +568,7 @@ int trdx_prepare(int ldn) {
 // to a multiple of 32), every other entry zeros; done[b] = 0 -> untouched (certificate failed: the Jacobi solves it; jrep[b] = b).
 // act / jrep: batch ints each (device).  ws: trdx_workspace_doubles(ldn, batch).
 int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
-               double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a) {
+               double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
   MUSED_REQUIRE(trdx_supports(ldn, need), "trdx_solve: unsupported shape (order %d, need %d)", ldn, need);
   TrdShape sh;
   sh.n = ldn; sh.ldn = ldn; sh.off = 0;
@@ -555,10 +576,10 @@ int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const in
   sh.need = need;
   sh.cert_all = cert_all ? 1 : 0;
   switch (ldn) {
-    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
-    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
-    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
-    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a);
+    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
+    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
+    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
+    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
   }
 }
 
@@ -600,7 +621,7 @@ extern "C" int mused_debug_trdx(double* G, int n, int need, int cert_all, int ba
 // Diagnostic: average time (ms, HIP events) of `reps` solves of the same `batch` matrices (restored from a copy before every
 // solve, outside the timed region); out_a_ms: the part up to the end of the tridiagonalisation kernel.
 extern "C" int mused_debug_trdx_time(const double* G, int n, int need, int batch, int reps, double* out_ms, double* out_a_ms,
-                                     int* out_done, void* stream) {
+                                     int* out_done, long long* out_prof, void* stream) {
   MUSED_REQUIRE(G && batch >= 1 && reps >= 1 && out_ms && trdx_supports(n, need), "mused_debug_trdx_time: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int rc = trdx_prepare(n);
@@ -619,7 +640,7 @@ extern "C" int mused_debug_trdx_time(const double* G, int n, int need, int batch
   for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
     MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
     MUSED_CHECK_HIP(hipEventRecord(e0, st));
-    rc = trdx_solve(work, n, need, false, batch, nullptr, ib, ib + batch, ib + 2 * batch, ws, st, nullptr, ea);
+    rc = trdx_solve(work, n, need, false, batch, nullptr, ib, ib + batch, ib + 2 * batch, ws, st, nullptr, ea, out_prof);
     MUSED_CHECK_HIP(hipEventRecord(e1, st));
     MUSED_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f, msa = 0.f;

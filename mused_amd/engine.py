@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import sys
 
 import numpy as np
@@ -150,6 +151,8 @@ class WindowEngine:
         self.defer = False
         self._defer_slot = 0
         self.knn_fallbacks = 0  # windows redone on the classic path because a candidate list overflowed
+        self._hop_lock = threading.Lock()
+        self.slot_keys = []
         self._hop = {}          # hopping windows: key -> workspace + stream position of the window it holds (knn_adjacency_hop)
         self.hop_windows = self.hop_reused = self.hop_recomputes = 0
         self._rsvd = None
@@ -177,6 +180,7 @@ class WindowEngine:
         """Start a window; defer=True: overflow / weak-pivot flags are left on the device for the caller (`window_flags`)."""
         self.defer = bool(defer)
         self._defer_slot = 0
+        self.slot_keys = []  # deferred flag word i of this window belongs to hop state slot_keys[i] (None: a plain kNN call)
         if self.defer:
             self._ovf8.zero_()
 
@@ -242,6 +246,7 @@ class WindowEngine:
                 self.score_events.append((e0, e1))
             if deferred:
                 self._defer_slot += 1  # the caller reads the word behind the window (window_flags)
+                self.slot_keys.append(None)
             elif int(self._ovf.item()) != 0:  # one small blocking read: direct callers get a finished result
                 self.knn_fallbacks += 1
                 fused = False
@@ -255,6 +260,16 @@ class WindowEngine:
                  stream_ptr())
         adj = Adjacency(mask, n)
         return (adj, idx) if want_idx else adj
+
+    def request_hop_reset(self, key) -> bool:
+        """The flag word of hop state `key` was raised (read behind the window): its next call starts from scratch.  Called from
+        the thread that reads the flags; a counter, so that a request can never be lost to the enqueueing thread's clear."""
+        st = self._hop.get(key)
+        if st is None:
+            return False
+        with self._hop_lock:
+            st["reset_req"] = st.get("reset_req", 0) + 1
+        return True
 
     # ---- f3: hopping windows with reuse across consecutive windows -----------------------
     def knn_adjacency_hop(self, rows, k: int, metric: str, key, lo: int):
@@ -282,17 +297,21 @@ class WindowEngine:
             st = self._hop[key] = dict(ws=torch.empty(nbytes, dtype=torch.uint8, device=self.device), n=n, cap=cap, d=d, kk=kk,
                                        lo=None, flag=torch.zeros(1, dtype=torch.int32, device=self.device))
         n_new = 0
-        if st["lo"] is not None and not st.get("reset") and 0 < lo - st["lo"] < n:
+        # a reader of the deferred flag words asks for a rebuild by raising st["reset_req"] (request_hop_reset: the label
+        # workers' thread); this thread only ever copies it -- a request between the read and the copy is seen next window
+        req = st.get("reset_req", 0)
+        if st["lo"] is not None and req == st.get("reset_seen", 0) and 0 < lo - st["lo"] < n:
             n_new = lo - st["lo"]
-        st["reset"] = False
+        st["reset_seen"] = req
         w = words_for(n)
         mask = torch.empty((n, w), dtype=torch.int64, device=self.device)
         deferred = self.defer and self._defer_slot < 8
         if deferred:
             # the flag word (sticky on the device until the state is rebuilt) goes to the window's flag words; whoever reads
-            # them later repeats a flagged window elsewhere and sets st["reset"], which makes the next call start from scratch
+            # them later repeats a flagged window elsewhere and calls request_hop_reset, which makes the next call start from scratch
             fptr = C.c_void_p(self._ovf8.data_ptr() + 4 * self._defer_slot)
             self._defer_slot += 1
+            self.slot_keys.append(key)
             call("mused_knn_fused_hop", ptr(X), _DT[X.dtype], n, d, X.stride(0), kk, m, ptr(st["ws"]), st["ws"].numel(), cap,
                  int(lo), int(n_new), None, ptr(mask), w, fptr, stream_ptr())
             st["lo"] = int(lo)

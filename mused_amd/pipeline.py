@@ -232,6 +232,7 @@ class StreamPipeline:
         """Independent per window: wait for the embedding, k-means (main.py:97)."""
         ev, red_pin, sig_pin, n_clusters, trigger, t_start = job[:6]
         flag_pin, reduced_dev, mods = job[6], job[7], job[8]
+        slot_keys, job_eng = (job[9], job[10]) if len(job) > 10 else ([], self.eng)
         torch.cuda.set_device(self._device)
         ev.synchronize()
         reduced_host, sigma_host = red_pin.numpy().copy(), sig_pin.numpy().copy()
@@ -247,8 +248,9 @@ class StreamPipeline:
                 # a candidate list overflowed / the final Cholesky-QR met a weak pivot / more edges than the optimistic
                 # bound: this window again, on the paths that have no such limits (rare; blocking on this worker only)
                 for i_, f_ in enumerate(flags_host[4:]):   # hopping-window reuse: rebuild that modality's state next window
-                    if f_ and i_ in self.eng._hop:
-                        self.eng._hop[i_]["reset"] = True
+                    key = slot_keys[i_] if i_ < len(slot_keys) else None   # (flag word i_ <-> the i_-th DEFERRED kNN call)
+                    if f_ and key is not None:
+                        job_eng.request_hop_reset(key)
                 reduced_dev, sigma_dev, flags_host = self._redo_window(mods)
                 reduced_host, sigma_host = reduced_dev.cpu().numpy(), sigma_dev.cpu().numpy()
             WindowEngine.check_rsvd_flags(flags_host)  # raised on the label worker, surfaces in flush()
@@ -287,6 +289,11 @@ class StreamPipeline:
                 flags_host = flags.cpu().numpy()
                 st.synchronize()
             self.redone_windows += 1
+            if self.redone_windows == 8 or (self.redone_windows > 8 and self.redone_windows % 64 == 0):
+                import warnings
+
+                warnings.warn(f"mused_amd: {self.redone_windows} windows of this stream were repeated on the fallback engine "
+                              "(candidate-list overflow / weak pivot / edge bound): correct, but several times slower", RuntimeWarning)
             return reduced, sigma, flags_host
 
     def _chain(self, fut, job):
@@ -340,7 +347,8 @@ class StreamPipeline:
                 flag_pin.copy_(flags, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        return (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced, mods)
+        # (slot -> hop-state key of this window's deferred flag words: the engine has moved on by the time a worker reads them)
+        return (ev, red_pin, sig_pin, n_clusters, trigger, t_start, flag_pin, reduced, mods, list(eng.slot_keys), eng)
 
     def _cluster_after(self, fut_job):
         return self._cluster(fut_job.result())

@@ -78,3 +78,46 @@ def test_pipeline_reuses_and_matches_reference_golden(monkeypatch, name, ratio):
         reused, windows = pipe.eng.hop_reused, pipe.eng.hop_windows
     assert np.array_equal(out.astype(np.int64), g["all_clusters"])
     assert windows >= 2 and reused == windows - 1
+
+
+def test_flagged_hop_state_is_reset_by_its_key_not_by_its_slot(monkeypatch):
+    """the deferred flag words are indexed by the window's DEFERRED kNN calls, the hop states by modality.  With
+    modality types ["text", ""] the text modality takes no flag slot, so the numeric modality's hop state (key 1) reports
+    in slot 0.  A raised word must reset THAT state (round 3 looked for key 0, found nothing, and the sticky flag repeated
+    every later window on the fallback engine)."""
+    from mused_amd import synth
+    from mused_amd.engine import WindowEngine
+    from mused_amd.pipeline import StreamPipeline
+    from oracle import mo_oracle as omo
+
+    monkeypatch.setenv("MUSED_HOP_REUSE", "1")
+    W, ratio, n = 300, 3, 1500
+    text, labels = synth.text_stream(n, 5)
+    X, _ = synth.blob_stream(n, 12, 5, n_centres=4)
+    X = X.astype(np.float64)
+    real = WindowEngine.window_flags
+    calls = {"n": 0, "reset": []}
+
+    def flags_with_one_raised(self, rsvd_flags):
+        out = real(self, rsvd_flags)
+        calls["n"] += 1
+        if calls["n"] == 2:          # second window: pretend its first deferred kNN call failed its certificate
+            out[4] = 1
+        return out
+
+    real_req = WindowEngine.request_hop_reset
+
+    def spy(self, key):
+        calls["reset"].append(key)
+        return real_req(self, key)
+
+    monkeypatch.setattr(WindowEngine, "window_flags", flags_with_one_raised)
+    monkeypatch.setattr(WindowEngine, "request_hop_reset", spy)
+    with StreamPipeline(W, 8, 10, 0, "sSVDMC", modality_types=["text", ""], step_window_ratio=ratio) as pipe:
+        out = pipe.run([text, X], labels)
+        redone, reused, windows = pipe.redone_windows, pipe.eng.hop_reused, pipe.eng.hop_windows
+    ref = omo.process_streaming_data([text, X], ["text", ""], W, 8, 10, 0, "sSVDMC", labels, step_window_ratio=ratio)
+    assert np.array_equal(np.asarray(out, dtype=np.int64), np.asarray(ref, dtype=np.int64))
+    assert calls["reset"] == [1]                      # the numeric modality's state, found through the slot -> key map
+    assert redone == 1                                # only the flagged window was repeated
+    assert windows >= 4 and reused <= windows - 2     # ... and one later window was rebuilt from scratch

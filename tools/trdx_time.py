@@ -11,7 +11,7 @@ from test_gpu_trd import fd_buffers
 L = _lib.lib()
 fn = L.mused_debug_trdx_time
 fn.restype = C.c_int
-fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]
 fj = L.mused_debug_eig_time
 fj.restype = C.c_int
 fj.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
@@ -24,7 +24,8 @@ for n, need, batch in cases:
     G = torch.from_numpy(np.stack([Gs[i % len(Gs)] for i in range(batch)])).cuda()
     ms, msa = C.c_double(), C.c_double()
     done = (C.c_int * batch)()
-    _lib.check(fn(ptr(G), n, need, batch, 3, C.byref(ms), C.byref(msa), done, stream_ptr()))
+    prof = torch.zeros(batch, 4, dtype=torch.int64, device="cuda")
+    _lib.check(fn(ptr(G), n, need, batch, 3, C.byref(ms), C.byref(msa), done, ptr(prof) if os.environ.get("TRDX_PROF") else None, stream_ptr()))
     line = f"order {n} top {need} batch {batch:4d}: direct {ms.value:8.3f} ms per solve (tridiagonalisation {msa.value:8.3f}), {sum(done)} of {batch} certified"
     if "--jacobi" in os.environ.get("TRDX_TIME", "--jacobi"):
         ev = torch.zeros(batch, n, dtype=torch.float64, device="cuda")
@@ -34,3 +35,6 @@ for n, need, batch in cases:
         _lib.check(fj(ptr(G), n, batch, 24, 2, ptr(ev), ptr(V), C.byref(mj), C.byref(err), stream_ptr()))
         line += f" | one-sided Jacobi {mj.value:8.3f} ms"
     print(line, flush=True)
+    if os.environ.get("TRDX_PROF"):
+        pr = prof.cpu().numpy().astype(np.float64).mean(axis=0) / 100.0   # s_memtime: 100 MHz -> us
+        print("      kernel A phases, us per matrix (thread 0): column + Householder %.0f | symv %.0f | reductions + w %.0f | panel update %.0f" % tuple(pr), flush=True)
