@@ -407,6 +407,23 @@ class StreamPipeline:
         fut_cluster = self._kpool.submit(self._cluster_after, fut_job)
         self._pending.append(self._pool.submit(self._chain_after, fut_cluster, fut_job))
 
+    def process_reduced(self, reduced: torch.Tensor, sigma: torch.Tensor, true_labels_window, trigger=None):
+        """Hand the label workers a window whose reduced matrix (W, m) is already on the device (current stream): k-means
+        (main.py:97) and the trace entry {trigger, sigma, raw, matched}.  For drivers that produce the embedding themselves
+        (`SwfdmcLanes`); the matching of `out` follows the order of the calls, `trace[i]["raw"]` is order independent."""
+        t_start = time.perf_counter()
+        n_clusters = len(np.unique(true_labels_window))
+        red_pin, sig_pin = self._get_pins(reduced, sigma)
+        red_pin.copy_(reduced, non_blocking=True)
+        sig_pin.copy_(sigma, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        job = (ev, red_pin, sig_pin, n_clusters, trigger, t_start, None, reduced, None, [], self.eng)
+        if self._pool is None:
+            self._chain(self._cluster(job), job)
+        else:
+            self._pending.append(self._pool.submit(self._chain, self._kpool.submit(self._cluster, job), job))
+
     def flush(self):
         """Wait for every window handed in so far; re-raises the first error a worker met (the remaining windows are
         still drained, so that nothing is in flight afterwards)."""
@@ -518,3 +535,98 @@ def process_streaming_data(results, data_modalities, modality_types, window_size
     results["all_clusters"] = clusters
     results["processing_time"] = (time.time_ns() - t0) / 1e9
     return results
+
+
+class SwfdmcLanes:
+    """The reference's SWFDMC approach (main.py:58-76: one SeqBasedSWFD over the rows of the fused W x W adjacency of every
+    window, d = W; get() transposed to (W, l) -> k-means -> matching) with the windows of a stream dealt to `lanes`
+    CONTIGUOUS blocks whose sketches advance in lock-step inside the same launches.  A block is preceded by ONE halo window
+    it does not own (MAIN(t) continues AUX(t - 1), AUX starts empty: the sequential sketch is reproduced exactly); the block
+    that starts at the beginning of the stream gets a window of empty rows instead.  R (main.py:61) is fixed by stream window
+    0.  Raw k-means labels are collected per window and the Hungarian chain (main.py:105-119) is replayed in stream order.
+
+        lanes = SwfdmcLanes(W, l, k, seed, n_lanes, R)      # R = max out-degree of window 0's fused adjacency
+        out = lanes.run(windows, labels)                     # windows[t] = list of modality tensors of stream window t
+    """
+
+    def __init__(self, W, ell, k, seed, lanes, R, modality_types=None, stream=None, assume_finite=False):
+        from .swfd import SeqBasedSWFD
+
+        self.W, self.ell, self.k, self.seed, self.lanes = int(W), int(ell), int(k), int(seed), int(lanes)
+        self.types = list(modality_types) if modality_types else None
+        self.pipe = StreamPipeline(W, ell, k, seed, "sSVDMC", modality_types=self.types, async_labels=True, stream=stream,
+                                   assume_finite=assume_finite)
+        self.sk = SeqBasedSWFD(N=self.W, R=float(R), d=self.W, sketch_dim=self.ell, lanes=self.lanes)
+        self.words = (self.W + 63) // 64
+        self._masks = torch.zeros((self.lanes, self.W, self.words), dtype=torch.int64, device="cuda")
+
+    @staticmethod
+    def r_of_first_window(mods, W, k, modality_types=None, seed=0):
+        """main.py:61 on the fused adjacency of stream window 0."""
+        with StreamPipeline(W, 2, k, seed, "sSVDMC", modality_types=modality_types, async_labels=False) as p:
+            types = p.types or [""] * len(mods)
+            adjs = [p._adjacency(_to_dev(m), t) for m, t in zip(mods, types)]
+            fused = p.eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
+            return p.eng.max_row_sq_norm(fused)
+
+    def step(self, mods_per_lane, labels_per_lane, triggers, want):
+        """One lock-step: lane p appends the fused adjacency of mods_per_lane[p] (None: a window of empty rows); lanes with
+        want[p] get their window's sketch, k-means and a trace entry under triggers[p]."""
+        eng, types = self.pipe.eng, None
+        for p, mods in enumerate(mods_per_lane):
+            if mods is None:
+                self._masks[p].zero_()
+                continue
+            types = self.types or [""] * len(mods)
+            eng.begin_window(False)
+            adjs = [self.pipe._adjacency(_to_dev(m), t) for m, t in zip(mods, types)]
+            fused = eng.fuse(adjs) if len(adjs) > 1 else adjs[0]
+            self._masks[p].copy_(fused.mask)
+        self.sk.fit_adjacency_lanes(self._masks)
+        if not any(want):
+            return
+        B, sigma, _ = self.sk.get_device()                     # (lanes, l, W)
+        for p in range(self.lanes):
+            if want[p]:
+                reduced = B[p].t().contiguous()                # main.py:73-76: (W, l)
+                self.pipe.process_reduced(reduced, sigma[p], labels_per_lane[p], trigger=triggers[p])
+
+    def run(self, windows, labels):
+        """windows: list over stream windows of lists of modality arrays / tensors (W rows each); labels: true labels per
+        window.  Returns all_clusters in stream order (the concatenated matched labels)."""
+        from . import distributed as mdist
+
+        K, Bn = len(windows), self.lanes
+        blocks = [mdist.block_partition(K, Bn, p) for p in range(Bn)]
+        steps = 1 + max(b1 - b0 for b0, b1 in blocks)
+        for t in range(steps):
+            mods, labs, trig, want = [], [], [], []
+            for b0, b1 in blocks:
+                idx = b0 - 1 + t                                 # t = 0: the halo window
+                own = t >= 1 and idx < b1
+                idx = min(idx, b1 - 1)                           # a shorter lane repeats its last window (results unused)
+                mods.append(windows[idx] if idx >= 0 else None)
+                labs.append(labels[idx] if idx >= 0 else None)
+                trig.append(idx)
+                want.append(own)
+            self.step(mods, labs, trig, want)
+        self.pipe.flush()
+        self.sk.check()
+        raw = {tr["trigger"]: tr["raw"] for tr in self.pipe.trace}
+        self.sigma = {tr["trigger"]: tr["sigma"] for tr in self.pipe.trace}
+        return mdist.replay_label_chain(np.array([raw[t] for t in range(K)], dtype=np.int64), mo.match_clusters)
+
+    def close(self):
+        self.pipe.close()
+        self.sk.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def _to_dev(m):
+    return m if isinstance(m, torch.Tensor) or not isinstance(m, np.ndarray) or m.dtype.kind not in "fiu" else torch.from_numpy(m).cuda()

@@ -79,6 +79,20 @@ class SeqBasedSWFD:
         self._keepalive = adj.mask
         return self
 
+    def fit_adjacency_lanes(self, masks: torch.Tensor):
+        """`fit_adjacency` for every lane at once: masks = (lanes, n, words) int64 CUDA tensor, the bitmask rows of one 0/1
+        adjacency per lane (n = d rows each; an all-zero mask is a window of empty rows -- the halo of a lane whose block
+        starts at the beginning of the stream).  The lanes advance in lock-step inside the same launches."""
+        if masks.dim() != 3 or masks.shape[0] != self.lanes or masks.shape[1] != self.d or not masks.is_cuda or masks.dtype != torch.int64:
+            raise ValueError(f"expected an int64 CUDA tensor of shape ({self.lanes}, {self.d}, words)")
+        if masks.shape[2] * 64 < self.d:
+            raise ValueError("bit rows shorter than d")
+        if not masks.is_contiguous():
+            masks = masks.contiguous()
+        call("mused_swfd_append_lanes", self._h, ptr(masks), BITS, masks.shape[1], masks.stride(1), masks.stride(0), stream_ptr())
+        self._keepalive = masks
+        return self
+
     def fit(self, X):
         if self.lanes != 1:
             raise ValueError("multi-lane sketch: use fit_lanes")

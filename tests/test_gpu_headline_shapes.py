@@ -100,3 +100,27 @@ def test_swfdmc_reference_wiring_at_w10000(tag):
             np.testing.assert_allclose(tr["sigma"], sig, rtol=0, atol=1e-8 * sig[0])
     assert np.array_equal(np.asarray(out, dtype=np.int64), g["all_clusters"].astype(np.int64))
     assert hashlib.sha256(np.asarray(out, dtype=np.int64).tobytes()).hexdigest() == str(g["labels_sha"])
+
+
+@pytest.mark.parametrize("n_lanes", [2, 3])
+def test_swfdmc_lanes_equal_the_sequential_specification(n_lanes):
+    """SWFDMC with the three fixture windows dealt to 2 / 3 lock-step lanes (each block preceded by its halo window, a window of
+    empty rows at the beginning of the stream; mused_amd.pipeline.SwfdmcLanes): singular values and event labels equal the
+    SEQUENTIAL oracle pipeline's fixture -- device lanes == specification (not reference: parity unpinned)."""
+    from mused_amd import synth
+    from mused_amd.pipeline import SwfdmcLanes
+
+    g = load_golden("swfdmc_w10k_m1_3win")
+    W, ell, k, seed, n_windows = (int(x) for x in g["meta"][:5])
+    d = int(g["meta"][5])
+    wins = [synth.stream_window("blob", t, W, d, seed) for t in range(n_windows)]
+    assert [synth.array_digest(np.concatenate([w[0] for w in wins]))] == [str(x) for x in g["input_digest"]]
+    windows = [[torch.from_numpy(w[0].astype(np.float64)).cuda()] for w in wins]
+    labels = [w[1] for w in wins]
+    R = SwfdmcLanes.r_of_first_window(windows[0], W, k)
+    with SwfdmcLanes(W, ell, k, seed, n_lanes, R, modality_types=[""]) as lanes:
+        out = lanes.run(windows, labels)
+        for t, sig in enumerate(g["sigma"]):
+            np.testing.assert_allclose(lanes.sigma[t], sig, rtol=0, atol=1e-8 * sig[0])
+    assert np.array_equal(np.asarray(out, dtype=np.int64), g["all_clusters"].astype(np.int64))
+    assert hashlib.sha256(np.asarray(out, dtype=np.int64).tobytes()).hexdigest() == str(g["labels_sha"])
