@@ -275,11 +275,22 @@ def run_swfdmc(args, cfg):
     x0 = torch.from_numpy(window_rows(cfg, args.kind, 0, args.seed)[0]).cuda()
     R = SwfdmcLanes.r_of_first_window([x0], W, k)
     del x0
-    lanes = SwfdmcLanes(W, ell, k, args.seed, B, R, modality_types=[""], assume_finite=True)
+    # lanes in G groups, each a SwfdmcLanes of its own on its own stream and host thread: the Gram / rotate GEMMs of one group
+    # overlap the eigensolver chain and the memory-bound passes (bit expansion, scatter) of the other
+    import threading
 
-    def lock_step(t):
+    G = args.sketch_groups if args.sketch_groups > 0 else (2 if B >= 4 else 1)
+    G = max(1, min(G, B))
+    bounds = [mdist.block_partition(B, G, g) for g in range(G)]
+    streams = [torch.cuda.Stream() for _ in range(G)]
+    groups = [SwfdmcLanes(W, ell, k, args.seed, l1 - l0, R, modality_types=[""], stream=streams[g], assume_finite=True)
+              for g, (l0, l1) in enumerate(bounds)]
+    lanes = groups[0]
+
+    def group_step(g, t):
+        l0, l1 = bounds[g]
         mods, labs, trig, want = [], [], [], []
-        for b0, b1 in blocks:
+        for b0, b1 in blocks[l0:l1]:
             idx = b0 - 1 + t
             own = t >= 1 and idx < b1
             gi = g0 + min(idx, b1 - 1)
@@ -287,7 +298,21 @@ def run_swfdmc(args, cfg):
             labs.append(host[gi][1] if gi >= 0 else None)
             trig.append(gi)
             want.append(own)
-        lanes.step(mods, labs, trig, want)
+        with torch.cuda.stream(streams[g]):
+            groups[g].step(mods, labs, trig, want)
+
+    def run_steps(t_lo, t_hi):
+        def drive(g):
+            torch.cuda.set_device(local_rank)  # the current device is per host thread
+            for t in range(t_lo, t_hi):
+                group_step(g, t)
+            groups[g].pipe.flush()
+            streams[g].synchronize()
+        ths = [threading.Thread(target=drive, args=(g,)) for g in range(G)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
 
     def bracket(fn):
         if world > 1:
@@ -295,7 +320,6 @@ def run_swfdmc(args, cfg):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn()
-        lanes.pipe.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -305,19 +329,25 @@ def run_swfdmc(args, cfg):
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         return float(tm.item())
 
-    lanes.sk.profile(True)
-    t_halo = bracket(lambda: lock_step(0))               # the halo lock-step (also the warm-up: plans, graphs, caches)
-    n_warm = len(lanes.pipe.latencies)
-    lanes.sk.profile(True)
-    elapsed = bracket(lambda: [lock_step(t) for t in range(1, 1 + blk)])
-    lanes.sk.check()
-    raw = {tr["trigger"]: tr["raw"] for tr in lanes.pipe.trace}
+    for gr in groups:
+        gr.sk.profile(True)
+    t_halo = bracket(lambda: run_steps(0, 1))            # the halo lock-step (also the warm-up: plans, graphs, caches)
+    n_warm = [len(gr.pipe.latencies) for gr in groups]
+    for gr in groups:
+        gr.sk.profile(True)
+    elapsed = bracket(lambda: run_steps(1, 1 + blk))
+    raw = {}
+    for gr in groups:
+        gr.sk.check()
+        raw.update({tr["trigger"]: tr["raw"] for tr in gr.pipe.trace})
     raw_local = np.array([raw[g0 + t] for t in range(K)], dtype=np.int64)
     raw_all = mdist.gather_raw_labels(raw_local, [K] * world, device=coll_dev)
     all_labels = mdist.replay_label_chain(raw_all, mo.match_clusters)
     if rank == 0:
-        direct, t_ms, n_launch, solved, _ta_ms = lanes.sk.profile_read_direct()
-        lat = np.array(lanes.pipe.latencies[n_warm:])
+        reads = [gr.sk.profile_read_direct() for gr in groups]
+        direct = all(r[0] for r in reads)
+        t_ms, n_launch, solved = sum(r[1] for r in reads), sum(r[2] for r in reads), sum(r[3] for r in reads)
+        lat = np.concatenate([np.array(gr.pipe.latencies[n0:]) for gr, n0 in zip(groups, n_warm)])
         fl = 4.0 * 256 ** 3 / 3 + 2.0 * 256 * 256 * 128 + 20 * 512 * 255 * 5.0 + 128 * 4.0 * 255 * 6.0
         roof = None
         if direct and n_launch:
@@ -339,7 +369,7 @@ def run_swfdmc(args, cfg):
                      "rule": "value = rows / (timed + halo lock-step x K / 100): every lane sketches one window it does not own "
                              "before its block; on a 100-window-per-GPU stream the K timed windows carry K / 100 of that lock-step"},
             "config": {"workload": cfg["name"], "stream": args.kind, "W": W, "d_features": d, "d_sketch": W, "l": ell, "k": k,
-                       "swfd_levels": lanes.sk.L, "R": R, "lanes": B,
+                       "swfd_levels": lanes.sk.L, "R": R, "lanes": B, "lane_groups": [l1 - l0 for l0, l1 in bounds],
                        "parallelism": f"windows sharded in contiguous blocks over {world} GPU(s) x {B} lock-step lane(s) per GPU",
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
                        "collective_backend": (dist.get_backend() if world > 1 else None),
@@ -350,7 +380,8 @@ def run_swfdmc(args, cfg):
             "note": "parity of this wiring at W = 10,000, lanes against the sequential specification over three windows: "
                     "tests/test_gpu_headline_shapes.py (oracle fixtures, PARITY UNPINNED: the reference's swfd submodule is absent)",
         }))
-    lanes.close()
+    for gr in groups:
+        gr.close()
     if world > 1:
         dist.destroy_process_group()
 

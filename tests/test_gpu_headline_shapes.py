@@ -20,20 +20,20 @@ def _need_gpu():
 
 def test_swfd_config3_orders_past_an_epoch_end():
     """d = 4096, l = 256 (BASELINE config 3's orders: rotations of order 512 on the blocked direct solver, queries of order
-    768 / 1024) with a reduced window N = 1,024 over 2,500 rows: dumps, two epoch ends with the AUX -> MAIN swap, expiry --
+    768 / 1024) with a reduced window N = 1,024 over 1,400 rows: dumps, an epoch end with the AUX -> MAIN swap, expiry --
     device == specification (the reference's swfd submodule is absent: parity unpinned), checked after every ragged block."""
     from mused_amd import synth
     from mused_amd.swfd import SeqBasedSWFD
     from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
 
-    N, d, ell, rows = 1024, 4096, 256, 2500
+    N, d, ell, rows = 1024, 4096, 256, 1400
     X, _ = synth.stream_window("blob", 0, rows, d, 0)
     X = X.astype(np.float64)
     R = float((X ** 2).sum(1).max())
     ora = OraSWFD(N=N, R=R, d=d, sketch_dim=ell)
     dev = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
     t = 0
-    for step in (700, 324, 1, 999, 476):       # crosses row 1024 and row 2048 (epoch ends), ragged in between
+    for step in (700, 324, 1, 375):            # crosses row 1024 (epoch end), ragged in between
         ora.fit(X[t:t + step])
         dev.fit(torch.from_numpy(X[t:t + step]).cuda())
         t += step

@@ -57,7 +57,7 @@ def test_reference_default_parameters_stream(approach):
     g = load_golden("bench_refdef_blob_s0")
     X, labels, (n_windows, W, d, ell, k, seed) = _bench_stream(g)
     if approach == "SWFDMC":
-        n_windows = 3
+        n_windows = 2
         X, labels = X[: n_windows * W], labels[: n_windows * W]
     with StreamPipeline(W, ell, k, seed, approach, modality_types=[""], async_labels=False) as pipe:
         out = np.asarray(pipe.run([X.astype(np.float64)], labels), dtype=np.int64)
