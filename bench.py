@@ -68,7 +68,7 @@ WORKLOADS = {
     # the reference's OWN use of the sketch (main.py:58-76, approach SWFDMC): SeqBasedSWFD over the rows of the fused W x W
     # adjacency (d = W = 10,000, bit rows), R from the first window, sketch transposed to (W, l) -> k-means -> matching.
     # Round 4: contiguous blocks of windows on lock-step lanes, each preceded by its halo window (mused_amd.pipeline.SwfdmcLanes).
-    "swfdmc": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=8,
+    "swfdmc": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=12,
                    name="SWFDMC wiring of main.py:58-76: features d=1024 -> kNN adjacency -> sketch over its W=10000 bit rows, l=128"),
 }
 PRE_STREAM = 1 << 20  # window indices of warm-up windows that would precede window 0 of the stream
@@ -279,7 +279,7 @@ def run_swfdmc(args, cfg):
     # overlap the eigensolver chain and the memory-bound passes (bit expansion, scatter) of the other
     import threading
 
-    G = args.sketch_groups if args.sketch_groups > 0 else (2 if B >= 4 else 1)
+    G = args.sketch_groups if args.sketch_groups > 0 else (3 if B >= 9 else (2 if B >= 4 else 1))
     G = max(1, min(G, B))
     bounds = [mdist.block_partition(B, G, g) for g in range(G)]
     streams = [torch.cuda.Stream() for _ in range(G)]

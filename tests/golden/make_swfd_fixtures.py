@@ -52,6 +52,32 @@ def case(tag, W, dims, ell, k, seed, n_windows):
     )
 
 
+def case_sketch_checks(tag, N, d, ell, steps, seed=0):
+    """SeqBasedSWFD of the specification over a ragged feature stream: after every block the singular values, the level, the
+    final shrink and a sampled 64 x 64 block of B^T B (the device test compares all of them).  Config 3's orders (l = 256:
+    rotations of order 512, queries of order 768 / 1024) with a reduced window so that epoch ends are crossed in minutes."""
+    rows = sum(steps)
+    X, _ = synth.stream_window("blob", 0, rows, d, seed)
+    X64 = X.astype(np.float64)
+    R = float((X64 ** 2).sum(1).max())
+    ora = OraSWFD(N=N, R=R, d=d, sketch_dim=ell)
+    idx = np.linspace(0, d - 1, 64).astype(np.int64)
+    sig, lvl, dlt, blk = [], [], [], []
+    t, t0 = 0, time.time()
+    for st in steps:
+        ora.fit(X64[t:t + st])
+        t += st
+        B, s, l, dd = ora.get()
+        sig.append(s)
+        lvl.append(l)
+        dlt.append(dd)
+        blk.append((B[:, idx].T @ B[:, idx]))
+    print(tag, "oracle sketch", round(time.time() - t0, 1), "s", flush=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", tag + ".npz"), meta=np.array([N, d, ell, seed] + list(steps)),
+                        input_digest=np.array(synth.array_digest(X)), R=np.array(R), sigma=np.array(sig), level=np.array(lvl),
+                        delta=np.array(dlt), gram_idx=idx, gram_block=np.array(blk))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]  # optional: tags to (re)generate
     cases = [
@@ -61,6 +87,10 @@ if __name__ == "__main__":
         # two Hungarian matching steps at d = W = 10,000 (round 4; ~30 CPU-minutes)
         ("swfdmc_w10k_m1_3win", 10000, (64,), 128, 50, 0, 3),
     ]
+    # the reference's own default parameters (main.py:305-313: window_size 2000, reduced_dim 50, k_basis 50), three windows
+    cases.append(("swfdmc_refdef_3win", 2000, (256,), 50, 50, 0, 3))
     for c in cases:
         if not only or c[0] in only:
             case(*c)
+    if not only or "swfd_c3orders" in only:
+        case_sketch_checks("swfd_c3orders", 1024, 4096, 256, (700, 324, 1, 999, 476))

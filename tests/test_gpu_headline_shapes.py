@@ -18,32 +18,33 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def test_swfd_config3_orders_past_an_epoch_end():
+def test_swfd_config3_orders_past_two_epoch_ends():
     """d = 4096, l = 256 (BASELINE config 3's orders: rotations of order 512 on the blocked direct solver, queries of order
-    768 / 1024) with a reduced window N = 1,024 over 1,400 rows: dumps, an epoch end with the AUX -> MAIN swap, expiry --
-    device == specification (the reference's swfd submodule is absent: parity unpinned), checked after every ragged block."""
+    768 / 1024) with a reduced window N = 1,024 over 2,500 rows: dumps, two epoch ends with the AUX -> MAIN swap, expiry --
+    device == specification after every ragged block, against tests/golden/swfd_c3orders.npz (outputs of oracle/swfd_oracle.py,
+    make_swfd_fixtures.py; the reference's swfd submodule is absent: parity unpinned)."""
     from mused_amd import synth
     from mused_amd.swfd import SeqBasedSWFD
-    from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
 
-    N, d, ell, rows = 1024, 4096, 256, 1400
-    X, _ = synth.stream_window("blob", 0, rows, d, 0)
-    X = X.astype(np.float64)
-    R = float((X ** 2).sum(1).max())
-    ora = OraSWFD(N=N, R=R, d=d, sketch_dim=ell)
-    dev = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
+    g = load_golden("swfd_c3orders")
+    N, d, ell, seed = (int(x) for x in g["meta"][:4])
+    steps = [int(x) for x in g["meta"][4:]]
+    X, _ = synth.stream_window("blob", 0, sum(steps), d, seed)
+    assert synth.array_digest(X) == str(g["input_digest"])
+    Xd = torch.from_numpy(X.astype(np.float64)).cuda()
+    dev = SeqBasedSWFD(N=N, R=float(g["R"]), d=d, sketch_dim=ell)
+    idx = g["gram_idx"]
     t = 0
-    for step in (700, 324, 1, 375):            # crosses row 1024 (epoch end), ragged in between
-        ora.fit(X[t:t + step])
-        dev.fit(torch.from_numpy(X[t:t + step]).cuda())
+    for i, step in enumerate(steps):          # crosses row 1024 and row 2048 (epoch ends), ragged in between
+        dev.fit(Xd[t:t + step])
         t += step
-        Bo, so, lo, do = ora.get()
         Bd, sd, ld, dd = dev.get()
-        assert ld == lo, t
+        so = g["sigma"][i]
+        assert ld == int(g["level"][i]), t
         np.testing.assert_allclose(sd, so, rtol=0, atol=1e-8 * so[0], err_msg=str(t))
-        np.testing.assert_allclose(Bd.T @ Bd, Bo.T @ Bo, rtol=0, atol=1e-8 * so[0] ** 2, err_msg=str(t))
+        np.testing.assert_allclose(dd, float(g["delta"][i]), rtol=1e-9, atol=1e-9 * so[0] ** 2)
+        np.testing.assert_allclose(Bd[:, idx].T @ Bd[:, idx], g["gram_block"][i], rtol=0, atol=1e-8 * so[0] ** 2, err_msg=str(t))
     dev.close()
-    assert t == rows
 
 
 def test_swfd_at_config3_shape_matches_oracle():

@@ -47,34 +47,34 @@ def _bench_stream(g, kind="blob"):
 
 @pytest.mark.parametrize("approach", ["sSVDMC", "SWFDMC"])
 def test_reference_default_parameters_stream(approach):
-    """The reference's own operating point (/root/reference/main.py:305-313: window_size 2000, reduced_dim 50, k_basis 50),
-    ten windows.  sSVDMC: `all_clusters` of the reference's window loop (golden bench_refdef_blob_s0) bit for bit -- the
-    eigenstep's r = 60 Gram on the direct solver.  SWFDMC: the same stream through the reference's wiring of the sketch
-    (rotations of order 100, queries of order 150, all on the direct solver) against the ORACLE pipeline (device ==
-    specification: the reference's swfd submodule is absent, parity unpinned)."""
+    """The reference's own operating point (/root/reference/main.py:305-313: window_size 2000, reduced_dim 50, k_basis 50).
+    sSVDMC: ten windows, `all_clusters` of the reference's window loop (golden bench_refdef_blob_s0) bit for bit -- the
+    eigenstep's r = 60 Gram on the direct solver.  SWFDMC: three windows of the same stream through the reference's wiring of
+    the sketch (rotations of order 100, queries of order 150, all on the direct solver) against the ORACLE pipeline's fixture
+    swfdmc_refdef_3win (device == specification: the reference's swfd submodule is absent, parity unpinned)."""
+    from mused_amd import synth
     from mused_amd.pipeline import StreamPipeline
 
-    g = load_golden("bench_refdef_blob_s0")
-    X, labels, (n_windows, W, d, ell, k, seed) = _bench_stream(g)
-    if approach == "SWFDMC":
-        n_windows = 2
-        X, labels = X[: n_windows * W], labels[: n_windows * W]
-    with StreamPipeline(W, ell, k, seed, approach, modality_types=[""], async_labels=False) as pipe:
-        out = np.asarray(pipe.run([X.astype(np.float64)], labels), dtype=np.int64)
-        trace = list(pipe.trace)
     if approach == "sSVDMC":
+        g = load_golden("bench_refdef_blob_s0")
+        X, labels, (n_windows, W, d, ell, k, seed) = _bench_stream(g)
+        with StreamPipeline(W, ell, k, seed, approach, modality_types=[""], async_labels=False) as pipe:
+            out = np.asarray(pipe.run([X.astype(np.float64)], labels), dtype=np.int64)
         assert np.array_equal(out.reshape(n_windows, W), g["labels"].astype(np.int64))
         assert hashlib.sha256(out.tobytes()).hexdigest()[:16] == str(g["cumulative_sha16"][n_windows - 1])
-    else:
-        from oracle import mo_oracle as omo
-        from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
-
-        otrace = []
-        ref = omo.process_streaming_data([X.astype(np.float64)], [""], W, ell, k, seed, "SWFDMC", labels, swfd_cls=OraSWFD,
-                                         trace=otrace)
-        for tr, orc in zip(trace, otrace):
-            np.testing.assert_allclose(tr["sigma"], orc["sigma"], rtol=0, atol=1e-8 * orc["sigma"][0])
-        assert np.array_equal(out, np.asarray(ref, dtype=np.int64))
+        return
+    g = load_golden("swfdmc_refdef_3win")
+    W, ell, k, seed, n_windows, d = (int(x) for x in g["meta"][:6])
+    assert (W, ell, k) == (2000, 50, 50)
+    wins = [synth.stream_window("blob", t, W, d, seed) for t in range(n_windows)]
+    X = np.concatenate([w[0] for w in wins])
+    labels = np.concatenate([w[1] for w in wins])
+    assert [synth.array_digest(X)] == [str(x) for x in g["input_digest"]]
+    with StreamPipeline(W, ell, k, seed, approach, modality_types=[""], async_labels=False) as pipe:
+        out = np.asarray(pipe.run([X.astype(np.float64)], labels), dtype=np.int64)
+        for tr, sig in zip(pipe.trace, g["sigma"]):
+            np.testing.assert_allclose(tr["sigma"], sig, rtol=0, atol=1e-8 * sig[0])
+    assert np.array_equal(out, g["all_clusters"].astype(np.int64))
 
 
 @pytest.mark.parametrize("name,ratio", [("c1_stream_hop2_blob_s0", 2), ("c1_stream_hop4_gauss_s1", 4)])
