@@ -48,6 +48,9 @@ struct EigPlan {
   const int* jrep;     // what the Jacobi's launch-per-round kernels test (matrix b runs when jrep[b] == b): rep, or -- behind the
                        // direct solver of orders 320 .. 512 (trdx.hip) -- the per-solve list of the matrices it rejected
   int *trdx_act, *trdx_jrep;  // trdx: matrices that passed (act[b] == b) / that the Jacobi must solve (jrep[b] == b)
+  int* trdx_nrej;             // trdx: device count of the matrices the last solve rejected
+  int* trdx_nrej_host;        // ... its pinned host copy: the Jacobi's sweep graph (hundreds of launches that would find nothing
+  hipEvent_t trdx_ev;         //     to do) is only launched when the count is not zero
   int trd_need;        // leading eigenpairs the caller reads
   int trd_cert_all;    // every one of them must pass the certificate (eigenstep) / those that survive the FD shrink
   double* trd_ws;
@@ -1164,6 +1167,9 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         MUSED_CHECK_HIP(hipMalloc(&p->trd_done, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMalloc(&p->trdx_act, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMalloc(&p->trdx_jrep, sizeof(int) * (size_t)batch));
+        MUSED_CHECK_HIP(hipMalloc(&p->trdx_nrej, sizeof(int)));
+        MUSED_CHECK_HIP(hipHostMalloc((void**)&p->trdx_nrej_host, sizeof(int), hipHostMallocDefault));
+        MUSED_CHECK_HIP(hipEventCreateWithFlags(&p->trdx_ev, hipEventDisableTiming));
         p->jrep = p->trdx_jrep;
       }
     }
@@ -1224,6 +1230,9 @@ void eig_plan_destroy(EigPlan* p) {
   if (p->trd_done) (void)hipFree(p->trd_done);
   if (p->trdx_act) (void)hipFree(p->trdx_act);
   if (p->trdx_jrep) (void)hipFree(p->trdx_jrep);
+  if (p->trdx_nrej) (void)hipFree(p->trdx_nrej);
+  if (p->trdx_nrej_host) (void)hipHostFree(p->trdx_nrej_host);
+  if (p->trdx_ev) (void)hipEventDestroy(p->trdx_ev);
   if (p->ev0) {
     for (size_t i = 0; i < p->ev0->size(); ++i) {
       (void)hipEventDestroy((*p->ev0)[i]);
@@ -1348,9 +1357,10 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));
     if (p->trd) {
+      if (p->trd == 2) MUSED_CHECK_HIP(hipMemsetAsync(p->trdx_nrej, 0, sizeof(int), st));
       const int rc = p->trd == 2
                          ? trdx_solve(p->Gc, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done, p->trdx_act,
-                                      p->trdx_jrep, p->trd_ws, st, rec ? p->work : nullptr,
+                                      p->trdx_jrep, p->trdx_nrej, p->trd_ws, st, rec ? p->work : nullptr,
                                       (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr)
                          : trd_solve(p->Gc, p->n, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done,
                                      p->trd_ws, st, nullptr, rec ? p->work : nullptr,
@@ -1361,7 +1371,23 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
         ++p->prof_n;
       }
     }
-    if (p->have_graph && allow_graph) {
+    bool run_jacobi = true;
+    if (p->trd == 2) {
+      // The blocked direct solver's fallback is the sweep graph: sweeps x rounds launches over the whole batch, each of which
+      // only finds out on the device that it has nothing to do (12 % of config 3's kernel time when it was launched
+      // unconditionally).  A rejection is rare, a solve of these orders takes milliseconds: the host waits for the count
+      // (an event on this stream: safe beside other threads' captures) and launches the graph only when it is not zero.
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cs);
+      if (cs == hipStreamCaptureStatusNone) {
+        MUSED_CHECK_HIP(hipMemcpyAsync(p->trdx_nrej_host, p->trdx_nrej, sizeof(int), hipMemcpyDeviceToHost, st));
+        MUSED_CHECK_HIP(hipEventRecord(p->trdx_ev, st));
+        MUSED_CHECK_HIP(hipEventSynchronize(p->trdx_ev));
+        run_jacobi = *p->trdx_nrej_host != 0;
+      }
+    }
+    if (!run_jacobi) {
+    } else if (p->have_graph && allow_graph) {
       MUSED_CHECK_HIP(hipGraphLaunch(p->exec, st));
     } else {
       const int rc = osj_enqueue_sweeps(p, st);

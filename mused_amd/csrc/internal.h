@@ -104,7 +104,7 @@ bool trdx_supports(int ldn, int need);
 size_t trdx_workspace_doubles(int ldn, int batch);
 int trdx_prepare(int ldn);
 int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
-               double* ws, hipStream_t st, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr,
+               int* nrej, double* ws, hipStream_t st, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr,
                long long* prof = nullptr);  // prof (device, batch x 4, diagnostic): s_memtime ticks per phase of kernel A
 
 }  // namespace mused

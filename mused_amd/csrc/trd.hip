@@ -412,6 +412,13 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
   __syncthreads();
   const double lam0 = sm[L_LAM], lamcut = sm[L_LAM + sh.need - 1];
   auto significant = [&](int c) -> bool { return c < sh.nvec && trd_significant(sm[L_LAM + c], c, lam0, lamcut, sh); };
+  if (t < 64) {  // largest residual among the significant vectors (widens the cluster rule)
+    double rmax = fmax(significant(t) ? sm[L_D + t] : 0.0, significant(t + 64) ? sm[L_D + t + 64] : 0.0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));
+    if (t == 0) sm[L_MISC + 10] = rmax;
+  }
+  __syncthreads();
   // certificate: cosines between neighbours in the spectrum, clusters wider than the neighbourhood
   {
     const int c = t >> 2, dl = (t & 3) + 1, c2 = c + dl;
@@ -422,9 +429,7 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
       if (!(fabs(dotv) * sm[L_ZS + c] * sm[L_ZS + c2] <= TRD_COS_MAX)) atomicOr(badflag, 2);
     }
     if ((t & 3) == 0 && c + 5 < TM && significant(c) && significant(c + 5)) {
-      double rmax = 0.0;  // largest residual among the significant vectors
-      for (int j = 0; j < sh.nvec; ++j) rmax = (significant(j) && sm[L_D + j] > rmax) ? sm[L_D + j] : rmax;
-      const double width = fmax(1e-7 * lam0, TRD_GAP_PER_RES * rmax * wsm[W_MI]);
+      const double width = fmax(1e-7 * lam0, TRD_GAP_PER_RES * sm[L_MISC + 10] * wsm[W_MI]);
       if ((sm[L_LAM + c] - sm[L_LAM + c + 5]) <= width) atomicOr(badflag, 4);
     }
   }

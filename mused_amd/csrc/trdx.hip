@@ -353,7 +353,8 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
 template <typename LY>
 __global__ __launch_bounds__(256) void trdx_cert_kernel(const int* __restrict__ rep, double* __restrict__ ws,
                                                         int* __restrict__ done, int* __restrict__ act, int* __restrict__ jrep,
-                                                        unsigned long long* __restrict__ work, const TrdShape sh) {
+                                                        int* __restrict__ nrej, unsigned long long* __restrict__ work,
+                                                        const TrdShape sh) {
   constexpr int TNX = LY::TNX, TMX = LY::TMX;
   __shared__ double lam[TMX], zs[TMX], rs[TMX];
   __shared__ int bad;
@@ -381,16 +382,22 @@ __global__ __launch_bounds__(256) void trdx_cert_kernel(const int* __restrict__ 
   }
   __syncthreads();
   const double width = fmax(1e-7 * lam0, TRD_GAP_PER_RES * rmax_s * wsm[LY::W_MI]);
-  for (int pr = t; pr < 4 * sh.nvec; pr += 256) {
-    const int c = pr >> 2, c2 = c + (pr & 3) + 1;
-    if (c2 < sh.nvec && significant(c) && significant(c2)) {
-      double dotv = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < TNX; ++i) dotv = fma(Zg[(long)i * TMX + c], Zg[(long)i * TMX + c2], dotv);
-      if (!(fabs(dotv) * zs[c] * zs[c2] <= TRD_COS_MAX)) atomicOr(&bad, 2);
+  // thread c: cosines of vector c with its 4 neighbours (lanes walk consecutive columns of Zg: coalesced), cluster rule
+  for (int c = t; c < sh.nvec; c += 256) {
+    if (!significant(c)) continue;
+    double dt[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nn = sh.nvec - 1 - c < 4 ? sh.nvec - 1 - c : 4;
+#pragma unroll 4
+    for (int i = 0; i < TNX; ++i) {
+      const double* zr = Zg + (long)i * TMX + c;
+      const double z0 = zr[0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dt[q] = fma(z0, q < nn ? zr[q + 1] : 0.0, dt[q]);
     }
-    if ((pr & 3) == 0 && c + 5 < sh.nvec && significant(c) && significant(c + 5) && (lam[c] - lam[c + 5]) <= width)
-      atomicOr(&bad, 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nn && significant(c + q + 1) && !(fabs(dt[q]) * zs[c] * zs[c + q + 1] <= TRD_COS_MAX)) atomicOr(&bad, 2);
+    if (c + 5 < sh.nvec && significant(c + 5) && (lam[c] - lam[c + 5]) <= width) atomicOr(&bad, 4);
   }
   __syncthreads();
   const bool ok = bad == 0;
@@ -398,6 +405,7 @@ __global__ __launch_bounds__(256) void trdx_cert_kernel(const int* __restrict__ 
     done[bm] = ok ? 1 : 0;
     act[bm] = ok ? bm : -1;
     jrep[bm] = ok ? -1 : bm;
+    if (!ok) atomicAdd(nrej, 1);
     if (ok && work) atomicAdd(work, 1ull);
   }
   if (!ok) return;
@@ -499,8 +507,8 @@ static int trdx_prepare_t() {
 }
 
 template <int NX>
-static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* rep, int* done, int* act, int* jrep, double* ws,
-                        hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
+static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* rep, int* done, int* act, int* jrep, int* nrej,
+                        double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
   using LY = LX<NX>;
   const long per = LY::W_PER;
   const int nvec = sh.nvec, nch32 = nvec / 32, nch16 = nvec / 16;
@@ -509,7 +517,7 @@ static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* re
   hipLaunchKernelGGL((trd_b_kernel<128, LY>), dim3(nch32 * batch), dim3(128), 0, st, rep, ws, sh);
   constexpr size_t c_lds = sizeof(double) * trd_c_lds_doubles<LY, 16>();
   hipLaunchKernelGGL((trd_c_kernel<LY, 16>), dim3(nch16 * batch), dim3(128), c_lds, st, rep, ws, sh);
-  hipLaunchKernelGGL(trdx_cert_kernel<LY>, dim3(batch), dim3(256), 0, st, rep, ws, done, act, jrep, work, sh);
+  hipLaunchKernelGGL(trdx_cert_kernel<LY>, dim3(batch), dim3(256), 0, st, rep, ws, done, act, jrep, nrej, work, sh);
   MUSED_LAUNCH_CHECK();
   int rc;
   // block Grams and triangular factors of the compact-WY blocks
@@ -566,9 +574,10 @@ int trdx_prepare(int ldn) {
 // Solves the matrices of Gc (batch x ldn x ldn column-major, symmetric, zero padded beyond the caller's order) in place:
 // done[b] = 1 -> columns 0 .. nvec - 1 of matrix b hold lam_j v_j for its largest eigenvalues (descending; nvec = `need` rounded up
 // to a multiple of 32), every other entry zeros; done[b] = 0 -> untouched (certificate failed: the Jacobi solves it; jrep[b] = b).
-// act / jrep: batch ints each (device).  ws: trdx_workspace_doubles(ldn, batch).
+// act / jrep: batch ints each (device); *nrej (device int, the caller clears it) += matrices rejected.
+// ws: trdx_workspace_doubles(ldn, batch).
 int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
-               double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
+               int* nrej, double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
   MUSED_REQUIRE(trdx_supports(ldn, need), "trdx_solve: unsupported shape (order %d, need %d)", ldn, need);
   TrdShape sh;
   sh.n = ldn; sh.ldn = ldn; sh.off = 0;
@@ -576,10 +585,10 @@ int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const in
   sh.need = need;
   sh.cert_all = cert_all ? 1 : 0;
   switch (ldn) {
-    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
-    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
-    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
-    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, ws, st, work, after_a, prof);
+    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
+    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
+    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
+    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
   }
 }
 
@@ -599,8 +608,9 @@ extern "C" int mused_debug_trdx(double* G, int n, int need, int cert_all, int ba
   double* ws = nullptr;
   int* ib = nullptr;
   MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trdx_workspace_doubles(n, batch)));
-  MUSED_CHECK_HIP(hipMalloc((void**)&ib, sizeof(int) * 2 * (size_t)batch));
-  rc = trdx_solve(G, n, need, cert_all != 0, batch, nullptr, out_done, ib, ib + batch, ws, st, nullptr, nullptr);
+  MUSED_CHECK_HIP(hipMalloc((void**)&ib, sizeof(int) * (2 * (size_t)batch + 1)));
+  MUSED_CHECK_HIP(hipMemsetAsync(ib + 2 * batch, 0, sizeof(int), st));
+  rc = trdx_solve(G, n, need, cert_all != 0, batch, nullptr, out_done, ib, ib + batch, ib + 2 * batch, ws, st, nullptr, nullptr);
   if (!rc) {
     const int nvec = ((need + 31) / 32) * 32;
     switch (n) {
@@ -631,7 +641,8 @@ extern "C" int mused_debug_trdx_time(const double* G, int n, int need, int batch
   const size_t bytes = sizeof(double) * (size_t)batch * n * n;
   MUSED_CHECK_HIP(hipMalloc((void**)&ws, sizeof(double) * trdx_workspace_doubles(n, batch)));
   MUSED_CHECK_HIP(hipMalloc((void**)&work, bytes));
-  MUSED_CHECK_HIP(hipMalloc((void**)&ib, sizeof(int) * 3 * (size_t)batch));
+  MUSED_CHECK_HIP(hipMalloc((void**)&ib, sizeof(int) * (3 * (size_t)batch + 1)));
+  MUSED_CHECK_HIP(hipMemset(ib + 3 * batch, 0, sizeof(int)));
   hipEvent_t e0, e1, ea;
   MUSED_CHECK_HIP(hipEventCreate(&e0));
   MUSED_CHECK_HIP(hipEventCreate(&e1));
@@ -640,7 +651,7 @@ extern "C" int mused_debug_trdx_time(const double* G, int n, int need, int batch
   for (int i = 0; i <= reps && !rc; ++i) {  // the first solve is a warm-up
     MUSED_CHECK_HIP(hipMemcpyAsync(work, G, bytes, hipMemcpyDeviceToDevice, st));
     MUSED_CHECK_HIP(hipEventRecord(e0, st));
-    rc = trdx_solve(work, n, need, false, batch, nullptr, ib, ib + batch, ib + 2 * batch, ws, st, nullptr, ea, out_prof);
+    rc = trdx_solve(work, n, need, false, batch, nullptr, ib, ib + batch, ib + 2 * batch, ib + 3 * batch, ws, st, nullptr, ea, out_prof);
     MUSED_CHECK_HIP(hipEventRecord(e1, st));
     MUSED_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f, msa = 0.f;
