@@ -16,6 +16,8 @@
 // golden window and on the 20-window benchmark stream).  An empty cluster (sklearn relocates its centre,
 // _k_means_common.pyx `_relocate_empty_clusters_dense`) is not handled here: it raises info[2] and the host falls back to
 // scikit-learn for that window.
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "internal.h"
@@ -101,6 +103,89 @@ __global__ __launch_bounds__(KM_CHUNK) void km_assign_kernel(const double* __res
   for (int e = t; e < k * d; e += KM_CHUNK) psum[(long)blockIdx.x * k * d + e] = sS[e];
 }
 
+// The same E step + M-step partials with the chunk's rows staged through LDS (round 4).  The kernel above gives every thread a
+// row and lets it read that row from global memory once per centre: 64 different cache lines per load instruction, the row
+// fetched k times -- 223 us per call at n = 10,000, d = 128, k = 8, ~50 calls per window, 4 % of the benchmark's kernel time
+// for 10 MFLOP.  Here a 256-row chunk travels as 256 / TR sub-tiles of TR rows, loaded coalesced into LDS (pitch d + 1);
+// PT = 256 / TR threads share a row (centres j = part, part + PT, ...: every dot product still runs over c = 0 .. d - 1 in
+// sequence, so the distances have the same bits) and agree on the first minimum by a lexicographic (distance, j) exchange;
+// the M-step partials add the rows of the chunk in the same order as before, from LDS.  Results are bit-identical to the
+// kernel above (same sums in the same order).
+template <int TR>
+__global__ __launch_bounds__(KM_CHUNK) void km_assign_tiled_kernel(const double* __restrict__ Xc, int n, int d, int k,
+                                                                  const double* __restrict__ C, const double* __restrict__ csq,
+                                                                  int* __restrict__ labels, const int* __restrict__ labels_old,
+                                                                  double* __restrict__ psum, int* __restrict__ pcnt,
+                                                                  KmInfo* __restrict__ info, int want_sums) {
+  constexpr int PT = KM_CHUNK / TR;
+  extern __shared__ __attribute__((aligned(16))) double km_lds[];
+  if (info->done) return;  // converged in an earlier iteration of this batch of launches
+  const int dp = d + 1;
+  double* sC = km_lds;                       // [k][dp]
+  double* sS = sC + (long)k * dp;            // [k][d]
+  double* xs = sS + (long)k * d;             // [TR][dp]
+  int* sL = reinterpret_cast<int*>(xs + (long)TR * dp);  // [KM_CHUNK]
+  const int t = threadIdx.x, r0 = blockIdx.x * KM_CHUNK;
+  for (int e = t; e < k * d; e += KM_CHUNK) {
+    const int j = e / d, c = e - j * d;
+    sC[(long)j * dp + c] = C[e];
+    sS[e] = 0.0;
+  }
+  const int rows = min(KM_CHUNK, n - r0);
+  const int row = t / PT, part = t % PT;
+  for (int sub = 0; sub * TR < rows; ++sub) {
+    const int rb = r0 + sub * TR, nr = min(TR, n - rb);
+    __syncthreads();  // the centres are staged / the previous sub-tile is consumed
+    for (int e = t; e < nr * d; e += KM_CHUNK) {
+      const int r = e / d, c = e - r * d;
+      xs[(long)r * dp + c] = Xc[(long)(rb + r) * d + c];
+    }
+    __syncthreads();
+    double best = 1.7976931348623157e308;
+    int lab = 0x7fffffff;
+    if (row < nr) {
+      const double* x = xs + (long)row * dp;
+      for (int j = part; j < k; j += PT) {
+        const double* cj = sC + (long)j * dp;
+        double dot = 0.0;
+        for (int c = 0; c < d; ++c) dot = fma(x[c], cj[c], dot);
+        const double dist = csq[j] - 2.0 * dot;
+        if (lab == 0x7fffffff || dist < best) {  // strict <: the first minimum wins, as in sklearn
+          best = dist;
+          lab = j;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < PT; o <<= 1) {  // the PT threads of a row are adjacent lanes
+      const double ob = __shfl_xor(best, o);
+      const int ol = __shfl_xor(lab, o);
+      if (ol != 0x7fffffff && (lab == 0x7fffffff || ob < best || (ob == best && ol < lab))) {
+        best = ob;
+        lab = ol;
+      }
+    }
+    if (part == 0 && row < nr) {
+      labels[rb + row] = lab;
+      if (labels_old && labels_old[rb + row] != lab) info->changed = 1;  // benign race: everybody writes 1
+      sL[sub * TR + row] = lab;
+    }
+    __syncthreads();
+    if (want_sums) {  // M-step partials: thread c owns column c and walks the sub-tile's rows in order (deterministic)
+      for (int c = t; c < d; c += KM_CHUNK)
+        for (int r = 0; r < nr; ++r) sS[(long)sL[sub * TR + r] * d + c] += xs[(long)r * dp + c];
+    }
+  }
+  if (!want_sums) return;
+  __syncthreads();
+  for (int j = t; j < k; j += KM_CHUNK) {  // k may exceed the chunk (k <= 1024, k * d <= 8192)
+    int cnt = 0;
+    for (int r = 0; r < rows; ++r) cnt += (sL[r] == j);
+    pcnt[(long)blockIdx.x * k + j] = cnt;
+  }
+  for (int e = t; e < k * d; e += KM_CHUNK) psum[(long)blockIdx.x * k * d + e] = sS[e];
+}
+
 // M step: centres from the chunk partials (chunks in order), total squared shift, stopping rule.  One workgroup.
 __global__ __launch_bounds__(1024) void km_update_kernel(const double* __restrict__ psum, const int* __restrict__ pcnt,
                                                         int nchunk, int k, int d, double* __restrict__ C,
@@ -183,14 +268,37 @@ int mused_kmeans_lloyd(const double* X, long ld, int n, int d, int k, const doub
   int* lab2 = (int*)w; w += 4l * n;
   w = (char*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
   KmInfo* info = (KmInfo*)w;
-  const size_t lds = 8 * 2 * (size_t)k * d + 4 * (KM_CHUNK + (size_t)k) + 16;
+  const size_t lds_plain = 8 * 2 * (size_t)k * d + 4 * (KM_CHUNK + (size_t)k) + 16;
+  // staged variant: the largest sub-tile (64 / 32 / 16 rows) whose LDS need fits; 0 = the row-per-thread kernel
+  auto tiled_lds = [&](int tr) -> size_t { return 8 * ((size_t)k * (d + 1) + (size_t)k * d + (size_t)tr * (d + 1)) + 4 * KM_CHUNK + 16; };
+  constexpr size_t LDS_MAX = 156 * 1024;
+  static const bool plain_only = [] {
+    const char* e = getenv("MUSED_KMEANS_ASSIGN");
+    return e && e[0] == 'p';
+  }();
+  const int tr = plain_only ? 0 : (tiled_lds(64) <= LDS_MAX ? 64 : (tiled_lds(32) <= LDS_MAX ? 32 : (tiled_lds(16) <= LDS_MAX ? 16 : 0)));
+  const size_t lds = tr ? tiled_lds(tr) : lds_plain;
   static std::once_flag once;
   static hipError_t aerr = hipSuccess;
   std::call_once(once, [] {
     aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(km_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * 2 * 8192 + 4 * (KM_CHUNK + 1024) + 16);
+    if (aerr == hipSuccess)
+      aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(km_assign_tiled_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (aerr == hipSuccess)
+      aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(km_assign_tiled_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (aerr == hipSuccess)
+      aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(km_assign_tiled_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
   });
   MUSED_CHECK_HIP(aerr);
+  auto assign = [&](int* cur_, const int* old_, int want) {
+    switch (tr) {
+      case 64: hipLaunchKernelGGL(km_assign_tiled_kernel<64>, dim3(nchunk), dim3(KM_CHUNK), lds, st, Xc, n, d, k, centers, csq, cur_, old_, psum, pcnt, info, want); break;
+      case 32: hipLaunchKernelGGL(km_assign_tiled_kernel<32>, dim3(nchunk), dim3(KM_CHUNK), lds, st, Xc, n, d, k, centers, csq, cur_, old_, psum, pcnt, info, want); break;
+      case 16: hipLaunchKernelGGL(km_assign_tiled_kernel<16>, dim3(nchunk), dim3(KM_CHUNK), lds, st, Xc, n, d, k, centers, csq, cur_, old_, psum, pcnt, info, want); break;
+      default: hipLaunchKernelGGL(km_assign_kernel, dim3(nchunk), dim3(KM_CHUNK), lds, st, Xc, n, d, k, centers, csq, cur_, old_, psum, pcnt, info, want);
+    }
+  };
   MUSED_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(KmInfo), st));
   hipLaunchKernelGGL(km_center_kernel, dim3(cdiv((long)n * d, 256)), dim3(256), 0, st, X, ld, mean, n, d, Xc);
   hipLaunchKernelGGL(km_csq_kernel, dim3(cdiv(k, 64)), dim3(64), 0, st, centers, k, d, csq);
@@ -202,8 +310,7 @@ int mused_kmeans_lloyd(const double* X, long ld, int n, int d, int k, const doub
   while (it < max_iter && !h.done) {
     const int batch = (max_iter - it) < 4 ? (max_iter - it) : 4;  // iterations between two reads of the stopping flag
     for (int b = 0; b < batch; ++b, ++it) {
-      hipLaunchKernelGGL(km_assign_kernel, dim3(nchunk), dim3(KM_CHUNK), lds, st, Xc, n, d, k, centers, csq, cur,
-                         it > 0 ? old : (const int*)nullptr, psum, pcnt, info, 1);
+      assign(cur, it > 0 ? old : (const int*)nullptr, 1);
       hipLaunchKernelGGL(km_update_kernel, dim3(1), dim3(1024), 0, st, psum, pcnt, nchunk, k, d, centers, csq, tol,
                          it == 0 ? 1 : 0, info);
       int* tmp = cur; cur = old; old = tmp;  // `old` now holds the labels of the iteration just queued
@@ -219,8 +326,7 @@ int mused_kmeans_lloyd(const double* X, long ld, int n, int d, int k, const doub
   if (h.done != 1 && !h.empty) {
     // not strictly converged: labels must match the final centres (one more E step, no update)
     MUSED_CHECK_HIP(hipMemsetAsync(&info->done, 0, sizeof(int), st));
-    hipLaunchKernelGGL(km_assign_kernel, dim3(nchunk), dim3(KM_CHUNK), lds, st, Xc, n, d, k, centers, csq, labels_out,
-                       (const int*)nullptr, psum, pcnt, info, 0);
+    assign(labels_out, (const int*)nullptr, 0);
     MUSED_LAUNCH_CHECK();
   } else if (last != labels_out) {
     MUSED_CHECK_HIP(hipMemcpyAsync(labels_out, last, 4l * n, hipMemcpyDeviceToDevice, st));
