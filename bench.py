@@ -53,7 +53,7 @@ WORKLOADS = {
     "c2": dict(W=10000, dims=(1024,), ell=128, k=50, lanes=20,
                name="synthetic d=1024 l=128 window=10000 k=50 (BASELINE config 2)"),
     # BASELINE.json configs[2]
-    "c3": dict(W=10000, dims=(4096,), ell=256, k=50, lanes=4,
+    "c3": dict(W=10000, dims=(4096,), ell=256, k=50, lanes=8,
                name="synthetic d=4096 l=256 window=10000 k=50 (BASELINE config 3)"),
     # BASELINE.json configs[3]: two 512-d modalities -> two kNN adjacencies -> OR-fusion (reference semantics,
     # main.py:45-56); the feature-row sketch sees the 1024-d concatenated rows
