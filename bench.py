@@ -777,6 +777,40 @@ def main():
                             "rocprofv3 average of trd_a_kernel under profiles/ is the same quantity).  Algorithmic bytes per "
                             "matrix: 256 KB read (lower triangle of G) + 512 KB of Householder vectors written.",
                 }
+                if n > 256:
+                    # orders 320 .. 512 run the BLOCKED solver (csrc/trdx.hip): its tridiagonalisation streams the lower triangle of
+                    # the matrix once per column -- bytes, not flops, are what it is priced on
+                    ldn = -(-n // 64) * 64
+                    bytes_a = ldn ** 3 // 6 * 8 + 2 * ldn * ldn * 8   # symv stream + the matrix read once + Householder vectors written
+                    gbs_a = per_launch * bytes_a / (a_us * 1e-6) / 1e9
+                    trx = None
+                    try:
+                        pmf = newest_profile("r*_pmc_trdx.json")
+                        if pmf:
+                            pm = json.load(open(pmf))
+                            trx = pm["per_kernel"]["trdx_a_kernel"]["traffic_bytes_per_matrix"] * per_launch
+                    except Exception:
+                        trx = None
+                    roof = {
+                        "kernel": f"trdx_a_kernel (blocked Householder tridiagonalisation of the direct eigensolver of the FD rotation, "
+                                  f"order {ldn}: one workgroup per Gram matrix, dlatrd panels of 16 columns, the symv streams the lower "
+                                  f"triangle of the panel-start matrix from L2 / Infinity Cache / HBM once per column), {per_launch:.1f} "
+                                  f"matrices solved per launch, {ns} independent launch streams",
+                        "bound": "hbm", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_a / HBM_PEAK_GBS,
+                        "traffic": trx, "launch_us": a_us, "launches_timed": n_launch,
+                        "matrices_solved_per_launch_avg": per_launch, "algorithmic_bytes_per_matrix": bytes_a,
+                        "per_cu": {"achieved_gbs": bytes_a / (a_us * 1e-6) / 1e9,
+                                   "note": "one workgroup = one CU per matrix: what a single CU pulls (64 B/clk of L1 = 150 GB/s is its ceiling)"},
+                        "concurrent_launch_streams": ns,
+                        "solve": {"kernels": "trdx_a -> trd_b -> trd_c -> trdx_cert -> block Grams + trdx_larft -> 3 GEMMs per block of 64 "
+                                             "reflectors -> trdx_store (one HIP-event bracket)", "launch_us": launch_us,
+                                  "flop_per_matrix": flop_solve, "achieved_tflops": tfl},
+                        "note": "algorithmic bytes = n^3 / 6 doubles of symv reads (every column multiplies the trailing lower triangle) + "
+                                "n^2 doubles read (working copy) + n^2 written (Householder vectors); `launch_us` is the HIP-event time from "
+                                "the start of the solver chain to the end of trdx_a_kernel on its launch stream with the other streams of "
+                                "the pipeline running beside it.  The kernel is latency-bound on the one tile (16 KB) a wave keeps in "
+                                "flight (DESIGN section 5b), far from the HBM roofline.",
+                    }
                 roof_hbm = {
                     "kernel": "the whole solver chain priced on bytes: G read once (512 KB), 128 columns written (256 KB) per matrix",
                     "bound": "hbm", "achieved": per_launch * 786432.0 / (launch_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,7 +1,9 @@
 """FETCH_SIZE / WRITE_SIZE of the direct eigensolver's kernels (csrc/trd.hip) from two rocprofv3 --pmc passes over
 tools/pmc_trd_run.py -> the JSON bench.py reads (profiles/rNN_pmc_trd.json):
 
-    python tools/pmc_trd_summarise.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <matrices per launch>
+    python tools/pmc_trd_summarise.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <matrices per launch> [trdx order]
+
+With a fourth argument (the order n of tools/pmc_trdx_run.py) the kernels of the blocked solver (csrc/trdx.hip) are summarised.
 
 Units and the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KB; FETCH_SIZE
 reports half the bytes of wide coalesced streaming reads and is doubled (an upper bound for the kernels whose reads are
@@ -20,11 +22,12 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mused::", "")
-        if name.startswith("trd_"):
+        if name.startswith("trd_") or name.startswith("trdx_") or (XN and name.startswith("gemm_f64_kernel")):
             acc[name.split("<")[0]].append(float(r["Counter_Value"]))
     return acc
 
 
+XN = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 batch = int(sys.argv[3])
@@ -35,8 +38,20 @@ algorithmic = {
     "trd_t_kernel": 254 * 256 * 8 + 16 * 256 * 8,          # Householder vectors read; 16 triangular factors written
     "trd_d_kernel": 254 * 256 * 8 + 256 * 128 * 8 + 16 * 256 * 8 + 256 * 256 * 8,  # V, Z, T read; 256 columns written
 }
+if XN:
+    n = XN
+    algorithmic = {
+        # symv stream of the lower triangle over the n columns + the matrix read once (working copy) + Householder vectors written
+        "trdx_a_kernel": n ** 3 // 6 * 8 + 2 * n * n * 8,
+        "trd_b_kernel": 3 * n * 8,
+        "trd_c_kernel": None,
+        "trdx_cert_kernel": None,
+        "trdx_larft_kernel": None,
+        "trdx_store_kernel": None,
+        "gemm_f64_kernel": None,
+    }
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --output-format csv -- python3 "
-                 f"tools/pmc_trd_run.py {batch}, MI355X (launches of {batch} matrices each)",
+                 f"tools/{'pmc_trdx_run.py ' + str(XN) if XN else 'pmc_trd_run.py'} {batch}, MI355X (launches of {batch} matrices each)",
        "matrices_per_launch": batch, "per_kernel": {}}
 tot = 0.0
 for k in sorted(set(fetch) | set(write)):
@@ -49,10 +64,14 @@ for k in sorted(set(fetch) | set(write)):
                             "write_bytes_per_matrix": wk * 1024.0 / batch, "traffic_bytes_per_matrix": t,
                             "algorithmic_bytes_per_matrix": algorithmic.get(k)}
 out["traffic_bytes_per_matrix"] = tot
-out["algorithmic_bytes_per_matrix_chain"] = 512 * 1024 + 256 * 1024
-out["note"] = ("chain = trd_a -> trd_b -> trd_c -> trd_t -> trd_d; the Householder vectors (512 KB), the eigenvectors of T (256 KB) "
-               "and the triangular factors travel through global scratch between the kernels, the lower half of the output "
-               "(256 KB of zeros) is written too: the chain's traffic is a few times its end-to-end algorithmic bytes (G read, "
-               "128 columns written) and still far below what HBM delivers in the chain's duration -- it is bound by dependent "
-               "steps, not bytes.")
+out["algorithmic_bytes_per_matrix_chain"] = (XN ** 3 // 6 * 8 + 2 * XN * XN * 8) if XN else 512 * 1024 + 256 * 1024
+if XN:
+    out["note"] = ("trdx_a_kernel streams the lower triangle of the panel-start matrix once per column (n^3 / 6 doubles) from L2 / "
+                   "Infinity Cache / HBM; the counters sit on the L2's memory side, so re-reads that hit the XCD's L2 are not in them")
+else:
+  out["note"] = ("chain = trd_a -> trd_b -> trd_c -> trd_t -> trd_d; the Householder vectors (512 KB), the eigenvectors of T (256 KB) "
+                 "and the triangular factors travel through global scratch between the kernels, the lower half of the output "
+                 "(256 KB of zeros) is written too: the chain's traffic is a few times its end-to-end algorithmic bytes (G read, "
+                 "128 columns written) and still far below what HBM delivers in the chain's duration -- it is bound by dependent "
+                 "steps, not bytes.")
 print(json.dumps(out, indent=1))
