@@ -20,7 +20,8 @@ struct OsjqCtl {
   unsigned head, tail;  // tickets handed to consumers / slots handed to producers
   int finished, nmat;   // matrices whose solve has ended / matrices that take part (representatives)
   int all_done, error;  // set once: nothing will ever be queued again / a consumer gave up waiting (timeout)
-  int pad[2];
+  int dirty;            // the unit ring holds entries of the last solve (it is only cleared when it does)
+  int pad;
 };
 
 struct EigPlan {
@@ -809,9 +810,10 @@ __global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict
   const unsigned pos = atomicAdd(&ctl->tail, (unsigned)upr);
   for (int i = 0; i < upr; ++i) q[pos + i] = 1u + (((unsigned)m * 256u + 0u) * 4u + (unsigned)i);
   atomicAdd(&ctl->nmat, 1);
+  ctl->dirty = 1;  // (benign race: everybody writes 1)
 }
 
-__global__ void osjq_reset_kernel(OsjqCtl* __restrict__ ctl) { ctl->tail = 0; ctl->nmat = 0; }
+__global__ void osjq_reset_kernel(OsjqCtl* __restrict__ ctl) { ctl->tail = 0; ctl->nmat = 0; ctl->dirty = 0; }
 // nothing was queued (every matrix skipped): the consumers must not wait for tickets that never come
 __global__ void osjq_seal_kernel(OsjqCtl* __restrict__ ctl) {
   if (ctl->nmat == 0) ctl->all_done = 1;
@@ -829,7 +831,10 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
   while (true) {
     if (threadIdx.x == 0) {
       unsigned item = OSJQ_EXIT;
-      const unsigned t = atomicAdd(&ctl->head, 1u);
+      // (nothing queued -- the usual case behind the direct solver, sealed before this launch -- or everything finished:
+      // leave without taking a ticket)
+      const bool over = __hip_atomic_load(&ctl->all_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      const unsigned t = over ? qcap : atomicAdd(&ctl->head, 1u);
       if (t < qcap) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
         while ((item = __hip_atomic_load(&q[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
@@ -907,7 +912,9 @@ __global__ void osjq_error_kernel(const OsjqCtl* __restrict__ ctl, int* __restri
   if (ctl->error) atomicOr(err_out, 1);
 }
 
-__global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n) {
+// the unit ring is cleared only when the previous solve queued something (behind the direct solver it hardly ever does)
+__global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n, const OsjqCtl* __restrict__ ctl) {
+  if (!ctl->dirty) return;
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) q[i] = 0u;
 }
@@ -915,13 +922,17 @@ __global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n) {
 template <int RP>
 static void osjq_launch(EigPlan* p, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB, upr = nb / 2;
-  hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap);
+  hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap, p->qctl);
   hipLaunchKernelGGL(osjq_reset_kernel, dim3(1), dim3(1), 0, st, p->qctl);
   hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->qclean,
                      p->batch, upr, p->rep, p->trd ? p->trd_done : (const int*)nullptr);
   if (p->trd) hipLaunchKernelGGL(osjq_seal_kernel, dim3(1), dim3(1), 0, st, p->qctl);
   long units = (long)p->batch * upr;
-  const int grid = (int)(units < 512 ? units : 512);  // 2 resident workgroups per CU; fewer than that is fine too
+  // 2 resident workgroups per CU; fewer than that is fine too (nobody waits for a particular workgroup to be resident).
+  // Behind the direct solver the queue only ever holds the few matrices its certificate rejected: a small grid then, so that
+  // the usual launch -- which finds nothing to do -- does not make 512 workgroups wait for 64 KB of LDS each
+  const long cap = p->trd ? 64 : 512;
+  const int grid = (int)(units < cap ? units : cap);
   hipLaunchKernelGGL((osjq_kernel<RP>), dim3(grid), dim3(256), 0, st, p->Gc, p->ldn, nb, p->batch, p->sweeps, p->sort_from,
                      p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone, p->qclean, p->q_timeout);
   if (p->err_out) hipLaunchKernelGGL(osjq_error_kernel, dim3(1), dim3(1), 0, st, p->qctl, p->err_out);
@@ -984,10 +995,11 @@ __global__ void osj_count_kernel(const int* __restrict__ notconv, int batch, int
 }
 
 // lam[b][j] = |column j| ; one wave per column
-__global__ void osj_norms_kernel(const double* __restrict__ Gc, int ldn, double* __restrict__ lam) {
+__global__ void osj_norms_kernel(const double* __restrict__ Gc, int ldn, double* __restrict__ lam, const int* __restrict__ skip) {
   const int col = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (col >= ldn) return;
   const int b = blockIdx.y, lane = threadIdx.x & 63;
+  if (skip && skip[b]) return;  // solved by a direct solver: it wrote the eigenvalues itself
   const double* c = Gc + ((long)b * ldn + col) * ldn;
   double s = 0.0;
   for (int r = lane; r < ldn; r += 64) s += c[r] * c[r];
@@ -1149,6 +1161,7 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         MUSED_CHECK_HIP(hipMalloc(&p->qdone, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMalloc(&p->qclean, sizeof(int) * (size_t)batch));
         MUSED_CHECK_HIP(hipMemset(p->qctl, 0, sizeof(OsjqCtl)));
+        MUSED_CHECK_HIP(hipMemset(p->q, 0, sizeof(unsigned) * (size_t)p->qcap));  // (cleared from now on only after use)
         const char* tq = getenv("MUSED_EIG_QUEUE_TIMEOUT_TICKS");  // test knob: 1 forces the give-up path
         p->q_timeout = tq ? strtoull(tq, nullptr, 10) : 300000000ull;
       }
@@ -1361,10 +1374,10 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
       const int rc = p->trd == 2
                          ? trdx_solve(p->Gc, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done, p->trdx_act,
                                       p->trdx_jrep, p->trdx_nrej, p->trd_ws, st, rec ? p->work : nullptr,
-                                      (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr)
+                                      (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr, nullptr, p->lam)
                          : trd_solve(p->Gc, p->n, p->ldn, p->trd_need, p->trd_cert_all != 0, p->batch, p->rep, p->trd_done,
                                      p->trd_ws, st, nullptr, rec ? p->work : nullptr,
-                                     (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr);
+                                     (rec && p->evm) ? (*p->evm)[p->prof_n] : nullptr, p->lam);
       if (rc) return rc;
       if (rec) {  // the events of a direct-solver plan bracket the direct solver alone (the Jacobi behind it only sees rejects)
         MUSED_CHECK_HIP(hipEventRecord((*p->ev1)[p->prof_n], st));
@@ -1400,7 +1413,8 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
         hipLaunchKernelGGL(osj_count_kernel, dim3(1), dim3(256), 0, st, p->notconv, p->batch, p->sweeps * p->rps, p->rps,
                            p->work, p->rep);
     }
-    hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam);
+    hipLaunchKernelGGL(osj_norms_kernel, dim3(cdiv(p->ldn, 4), p->batch), dim3(256), 0, st, p->Gc, p->ldn, p->lam,
+                       p->trd ? p->trd_done : (const int*)nullptr);
     if (evals)
       hipLaunchKernelGGL(osj_extract_kernel, dim3(cdiv((long)p->n * p->n, 256), p->batch), dim3(256), 0, st, p->Gc, p->lam,
                          p->n, p->ldn, evals, V);

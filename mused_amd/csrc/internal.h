@@ -97,7 +97,8 @@ size_t trd_workspace_doubles(int batch);
 int trd_prepare();
 bool trd_supports(int n, int ldn, int need);
 int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
-              hipStream_t st, long long* dbg_clk = nullptr, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr);
+              hipStream_t st, long long* dbg_clk = nullptr, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr,
+              double* lam_out = nullptr);  // lam_out (batch x ldn, optional): eigenvalues of the solved matrices (zeros behind them)
 
 // trdx.hip: blocked direct solver for padded orders 320, 384, 448, 512 (need rounded up to 32 <= order / 2)
 bool trdx_supports(int ldn, int need);
@@ -105,6 +106,7 @@ size_t trdx_workspace_doubles(int ldn, int batch);
 int trdx_prepare(int ldn);
 int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
                int* nrej, double* ws, hipStream_t st, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr,
-               long long* prof = nullptr);  // prof (device, batch x 4, diagnostic): s_memtime ticks per phase of kernel A
+               long long* prof = nullptr,   // prof (device, batch x 4, diagnostic): s_memtime ticks per phase of kernel A
+               double* lam_out = nullptr);  // lam_out (batch x ldn, optional): eigenvalues of the solved matrices
 
 }  // namespace mused

@@ -387,7 +387,7 @@ constexpr int DM_TM = DM_VB + 16 * 272;  // [16][16]    T
 constexpr int DM_TOTAL = DM_TM + 256;
 __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, const int* __restrict__ rep,
                                                        int* __restrict__ done, double* __restrict__ ws, TrdDebug dbg,
-                                                       const TrdShape sh) {
+                                                       const TrdShape sh, double* __restrict__ lam_out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
   if (rep && rep[bm] != bm) {  // (the Jacobi skips it too)
@@ -528,6 +528,9 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
           if (col + TM < ldn) G[(long)(col + TM) * ldn + i] = 0.0;
         }
       }
+    // the column norms the caller reads next are the eigenvalues themselves (|lam_c v_c| = lam_c): written here, the norms
+    // pass over the matrix is skipped for solved matrices
+    if (lam_out && t < ldn) lam_out[(long)bm * ldn + t] = (t < ncol && sm[L_LAM + t] > 0.0) ? sm[L_LAM + t] : 0.0;
     const int npad = ldn - n;  // padding rows of the Jacobi's layout
     for (int idx = t; idx < npad * ldn; idx += TNT) {
       const int c = idx / npad;
@@ -570,7 +573,7 @@ bool trd_supports(int n, int ldn, int need) { return n >= 2 && n <= TN && ldn >=
 // Jacobi).  `need`: how many leading pairs the caller reads; cert_all: see TrdShape.  ws: trd_workspace_doubles(batch)
 // doubles.  Five launches on `st`.
 int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
-              hipStream_t st, long long* dbg_clk, unsigned long long* work, hipEvent_t after_a) {
+              hipStream_t st, long long* dbg_clk, unsigned long long* work, hipEvent_t after_a, double* lam_out) {
   MUSED_REQUIRE(trd_supports(n, ldn, need), "trd_solve: unsupported shape (n=%d, ld=%d, need=%d)", n, ldn, need);
   TrdDebug dbg{dbg_clk, work};
   TrdShape sh;
@@ -586,7 +589,7 @@ int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, co
   else hipLaunchKernelGGL((trd_b_kernel<512, L256>), dim3(batch), dim3(512), 0, st, rep, ws, sh);
   hipLaunchKernelGGL((trd_c_kernel<L256, 32>), dim3(nch * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws, sh);
   hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(64), 0, st, rep, ws, sh);
-  hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg, sh);
+  hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg, sh, lam_out);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) void trdx_larft_kernel(const int* __restrict__ 
 // ================= result: column c of the matrix <- lam_c v_c (c < nvec), zeros elsewhere; 64 x 64 tiles through LDS ========
 template <typename LY>
 __global__ __launch_bounds__(256) void trdx_store_kernel(const int* __restrict__ act, const double* __restrict__ ws,
-                                                         double* __restrict__ Gc, const TrdShape sh) {
+                                                         double* __restrict__ Gc, const TrdShape sh, double* __restrict__ lam_out) {
   constexpr int TNX = LY::TNX, TMX = LY::TMX, NT = TNX / 64;
   __shared__ double tile[64][65];
   const int bm = blockIdx.y;
@@ -464,6 +464,11 @@ __global__ __launch_bounds__(256) void trdx_store_kernel(const int* __restrict__
   const double* wsm = ws + (long)bm * LY::W_PER;
   const double* Zb = wsm + LY::W_ZB;
   double* G = Gc + (long)bm * TNX * TNX;
+  if (lam_out && blockIdx.x == 0)  // the column norms the caller reads next: the eigenvalues themselves
+    for (int cc = threadIdx.x; cc < TNX; cc += 256) {
+      const double lv = cc < sh.nvec ? wsm[LY::W_LG + cc] : 0.0;
+      lam_out[(long)bm * TNX + cc] = lv > 0.0 ? lv : 0.0;
+    }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = 64 * tc + tx;
   const double lc = c < sh.nvec ? wsm[LY::W_LG + c] : 0.0;
@@ -508,7 +513,7 @@ static int trdx_prepare_t() {
 
 template <int NX>
 static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* rep, int* done, int* act, int* jrep, int* nrej,
-                        double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
+                        double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof, double* lam_out) {
   using LY = LX<NX>;
   const long per = LY::W_PER;
   const int nvec = sh.nvec, nch32 = nvec / 32, nch16 = nvec / 16;
@@ -543,7 +548,7 @@ static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* re
                            act)))
       return rc;
   }
-  hipLaunchKernelGGL(trdx_store_kernel<LY>, dim3((NX / 64) * (NX / 64), batch), dim3(256), 0, st, act, ws, Gc, sh);
+  hipLaunchKernelGGL(trdx_store_kernel<LY>, dim3((NX / 64) * (NX / 64), batch), dim3(256), 0, st, act, ws, Gc, sh, lam_out);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
 }
@@ -577,7 +582,8 @@ int trdx_prepare(int ldn) {
 // act / jrep: batch ints each (device); *nrej (device int, the caller clears it) += matrices rejected.
 // ws: trdx_workspace_doubles(ldn, batch).
 int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, int* act, int* jrep,
-               int* nrej, double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof) {
+               int* nrej, double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof,
+               double* lam_out) {
   MUSED_REQUIRE(trdx_supports(ldn, need), "trdx_solve: unsupported shape (order %d, need %d)", ldn, need);
   TrdShape sh;
   sh.n = ldn; sh.ldn = ldn; sh.off = 0;
@@ -585,10 +591,10 @@ int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const in
   sh.need = need;
   sh.cert_all = cert_all ? 1 : 0;
   switch (ldn) {
-    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
-    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
-    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
-    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof);
+    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
+    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
+    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
+    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
   }
 }
 
