@@ -530,7 +530,12 @@ __global__ __launch_bounds__(TNT, 1) void trd_d_kernel(double* __restrict__ Gc, 
       }
     // the column norms the caller reads next are the eigenvalues themselves (|lam_c v_c| = lam_c): written here, the norms
     // pass over the matrix is skipped for solved matrices
-    if (lam_out && t < ldn) lam_out[(long)bm * ldn + t] = (t < ncol && sm[L_LAM + t] > 0.0) ? sm[L_LAM + t] : 0.0;
+    // (an eigenvalue whose square underflows is written as zero, as the norm of its column would come out: the spectrum of
+    // an all-zero matrix is then exactly zero)
+    if (lam_out && t < ldn) {
+      const double lv = t < ncol ? sm[L_LAM + t] : 0.0;
+      lam_out[(long)bm * ldn + t] = (lv > 0.0 && lv * lv > 0.0) ? lv : 0.0;
+    }
     const int npad = ldn - n;  // padding rows of the Jacobi's layout
     for (int idx = t; idx < npad * ldn; idx += TNT) {
       const int c = idx / npad;

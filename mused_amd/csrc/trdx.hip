@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void trdx_store_kernel(const int* __restrict__
   if (lam_out && blockIdx.x == 0)  // the column norms the caller reads next: the eigenvalues themselves
     for (int cc = threadIdx.x; cc < TNX; cc += 256) {
       const double lv = cc < sh.nvec ? wsm[LY::W_LG + cc] : 0.0;
-      lam_out[(long)bm * TNX + cc] = lv > 0.0 ? lv : 0.0;
+      lam_out[(long)bm * TNX + cc] = (lv > 0.0 && lv * lv > 0.0) ? lv : 0.0;  // (as the norm of the column would come out)
     }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = 64 * tc + tx;
