@@ -814,17 +814,13 @@ __global__ void osjq_init_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict
 }
 
 __global__ void osjq_reset_kernel(OsjqCtl* __restrict__ ctl) { ctl->tail = 0; ctl->nmat = 0; ctl->dirty = 0; }
-// nothing was queued (every matrix skipped): the consumers must not wait for tickets that never come
-__global__ void osjq_seal_kernel(OsjqCtl* __restrict__ ctl) {
-  if (ctl->nmat == 0) ctl->all_done = 1;
-}
-
 template <int RP>
 __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, int ldn, int nb, int batch, int max_sweeps,
                                                      int sort_from, int* __restrict__ notconv,
                                                      const double* __restrict__ trace, unsigned* __restrict__ q,
                                                      unsigned qcap, OsjqCtl* __restrict__ ctl, int* __restrict__ qdone,
-                                                     int* __restrict__ qclean, unsigned long long timeout) {
+                                                     int* __restrict__ qclean, unsigned long long timeout,
+                                                     int* __restrict__ err_out) {
   __shared__ OsjwShared<RP, 8> sh;
   __shared__ unsigned s_item;
   const int rounds = nb - 1, upr = nb / 2;
@@ -846,6 +842,7 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
           if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {  // (3 s by default) give up, tell everyone
             __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl->all_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (err_out) atomicOr(err_out, 1);  // the caller's status word: the results of this solve are invalid
             item = OSJQ_EXIT;
             break;
           }
@@ -907,11 +904,6 @@ __global__ __launch_bounds__(256, 2) void osjq_kernel(double* __restrict__ Gc, i
   }
 }
 
-// after the persistent launch: a timeout inside it leaves partially rotated matrices behind -- tell the caller's status word
-__global__ void osjq_error_kernel(const OsjqCtl* __restrict__ ctl, int* __restrict__ err_out) {
-  if (ctl->error) atomicOr(err_out, 1);
-}
-
 // the unit ring is cleared only when the previous solve queued something (behind the direct solver it hardly ever does)
 __global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n, const OsjqCtl* __restrict__ ctl) {
   if (!ctl->dirty) return;
@@ -919,14 +911,59 @@ __global__ void osjq_zero_kernel(unsigned* __restrict__ q, unsigned n, const Osj
   if (i < n) q[i] = 0u;
 }
 
+// Behind the direct solver (one launch instead of five): the ring is cleared if the last solve used it, the control block
+// reset, the matrices the certificate rejected queued -- with the trace / flag set-up the Jacobi needs for them
+// (osj_begin_kernel's work, for those matrices only) -- and the queue sealed when there are none.  One workgroup.
+__global__ __launch_bounds__(1024) void osjq_prep_direct_kernel(OsjqCtl* __restrict__ ctl, unsigned* __restrict__ q, unsigned qcap,
+                                                               int* __restrict__ qdone, int* __restrict__ qclean, int batch,
+                                                               int upr, const int* __restrict__ rep, const int* __restrict__ skip,
+                                                               const double* __restrict__ Gc, int ldn, int nflag,
+                                                               double* __restrict__ trace, int* __restrict__ notconv) {
+  __shared__ int s_dirty;
+  const int t = threadIdx.x;
+  if (t == 0) s_dirty = ctl->dirty;
+  __syncthreads();
+  if (s_dirty)
+    for (unsigned i = t; i < qcap; i += 1024) q[i] = 0u;
+  __syncthreads();
+  if (t == 0) {
+    ctl->head = 0; ctl->tail = 0; ctl->finished = 0; ctl->nmat = 0; ctl->all_done = 0; ctl->error = 0; ctl->dirty = 0;
+  }
+  __syncthreads();
+  for (int m = t; m < batch; m += 1024) {
+    qdone[m] = 0;
+    qclean[m] = 0;
+    if (rep && rep[m] != m) continue;
+    if (skip && skip[m]) continue;  // solved by the direct solver
+    if (trace) {
+      const double* M = Gc + (long)m * ldn * ldn;
+      double sacc = 0.0;
+      for (int i = 0; i < ldn; ++i) sacc += fabs(M[(long)i * ldn + i]);
+      trace[m] = sacc;
+      for (int f = 0; f < nflag; ++f) notconv[(long)f * batch + m] = 0;
+    }
+    const unsigned pos = atomicAdd(&ctl->tail, (unsigned)upr);
+    for (int i = 0; i < upr; ++i) q[pos + i] = 1u + (((unsigned)m * 256u + 0u) * 4u + (unsigned)i);
+    atomicAdd(&ctl->nmat, 1);
+    ctl->dirty = 1;
+  }
+  __syncthreads();
+  if (t == 0 && ctl->nmat == 0) ctl->all_done = 1;  // nothing queued: the consumers leave at once
+}
+
 template <int RP>
 static void osjq_launch(EigPlan* p, hipStream_t st) {
   const int nb = p->ldn / OSJ_CB, upr = nb / 2;
-  hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap, p->qctl);
-  hipLaunchKernelGGL(osjq_reset_kernel, dim3(1), dim3(1), 0, st, p->qctl);
-  hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->qclean,
-                     p->batch, upr, p->rep, p->trd ? p->trd_done : (const int*)nullptr);
-  if (p->trd) hipLaunchKernelGGL(osjq_seal_kernel, dim3(1), dim3(1), 0, st, p->qctl);
+  if (p->trd) {
+    hipLaunchKernelGGL(osjq_prep_direct_kernel, dim3(1), dim3(1024), 0, st, p->qctl, p->q, p->qcap, p->qdone, p->qclean, p->batch,
+                       upr, p->rep, p->trd_done, p->Gc, p->ldn, p->notconv ? p->sweeps * p->rps : 0, p->notconv ? p->trace : nullptr,
+                       p->notconv);
+  } else {
+    hipLaunchKernelGGL(osjq_zero_kernel, dim3(cdiv(p->qcap, 1024)), dim3(1024), 0, st, p->q, p->qcap, p->qctl);
+    hipLaunchKernelGGL(osjq_reset_kernel, dim3(1), dim3(1), 0, st, p->qctl);
+    hipLaunchKernelGGL(osjq_init_kernel, dim3(cdiv(p->batch, 256)), dim3(256), 0, st, p->qctl, p->q, p->qdone, p->qclean,
+                       p->batch, upr, p->rep, (const int*)nullptr);
+  }
   long units = (long)p->batch * upr;
   // 2 resident workgroups per CU; fewer than that is fine too (nobody waits for a particular workgroup to be resident).
   // Behind the direct solver the queue only ever holds the few matrices its certificate rejected: a small grid then, so that
@@ -934,8 +971,7 @@ static void osjq_launch(EigPlan* p, hipStream_t st) {
   const long cap = p->trd ? 64 : 512;
   const int grid = (int)(units < cap ? units : cap);
   hipLaunchKernelGGL((osjq_kernel<RP>), dim3(grid), dim3(256), 0, st, p->Gc, p->ldn, nb, p->batch, p->sweeps, p->sort_from,
-                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone, p->qclean, p->q_timeout);
-  if (p->err_out) hipLaunchKernelGGL(osjq_error_kernel, dim3(1), dim3(1), 0, st, p->qctl, p->err_out);
+                     p->notconv, p->trace, p->q, p->qcap, p->qctl, p->qdone, p->qclean, p->q_timeout, p->err_out);
 }
 
 // orders <= 256: round 0 carries the pairs inside the blocks, nb - 1 launches per sweep
@@ -1364,8 +1400,8 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t st, b
     const long per = (long)p->ldn * p->ldn;
     if (!p->direct)
       hipLaunchKernelGGL(osj_pack_kernel, dim3(cdiv(per, 256), p->batch), dim3(256), 0, st, p->G[0], p->n, p->ldn, p->Gc);
-    if (p->notconv)
-      hipLaunchKernelGGL(osj_begin_kernel, dim3(p->batch), dim3(64), 0, st, p->Gc, p->ldn, p->sweeps * p->rps, p->trace,
+    if (p->notconv && !(p->trd == 1))  // (behind the register-resident direct solver the queue's set-up kernel does it, for the
+      hipLaunchKernelGGL(osj_begin_kernel, dim3(p->batch), dim3(64), 0, st, p->Gc, p->ldn, p->sweeps * p->rps, p->trace,   // rejected matrices only)
                          p->notconv);
     const bool rec = p->prof && p->ev0 && p->prof_n < (int)p->ev0->size();
     if (rec) MUSED_CHECK_HIP(hipEventRecord((*p->ev0)[p->prof_n], st));

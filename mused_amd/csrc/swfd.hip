@@ -129,8 +129,10 @@ __global__ void swfd_set_now_kernel(long long* now, long long v) { *now = v; }
 // after ~32 of 78).  Exact: every get() returns what it would have returned; only `export_half(0)` of a dead level
 // shows the frozen state.  (Never in the first epoch of a stream, where the AUX chain borrows MAIN's solves.)
 __global__ void swfd_rep_kernel(const int* __restrict__ meta, int L, int nchains, int* __restrict__ rep, int twin,
-                                const long long* __restrict__ dropped, long long epoch_start, int skip_dead) {
+                                const long long* __restrict__ dropped, long long epoch_start, int skip_dead,
+                                long long* __restrict__ now_dev, long long now) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *now_dev = now;  // (the rotation's time stamp: one launch less than a kernel of its own)
   if (c >= nchains) return;
   // first epoch of a stream: AUX is the twin of MAIN (both started empty) -> the AUX chain maps onto the MAIN chain
   const int base = ((twin && (c & 1)) ? c - 1 : c) * L;  // sketch index = lane * 2L + kind * L + level = chain * L + level
@@ -310,10 +312,12 @@ __global__ void swfd_scatter_kernel(const double* __restrict__ T, const int* __r
 static int swfd_rotate_all(Swfd* h, hipStream_t st) {
   const int S = h->S, n2 = h->n2, d = h->d, ell = h->ell;
   int rc;
-  hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
   if (h->rep)
     hipLaunchKernelGGL(swfd_rep_kernel, dim3(cdiv(2 * h->lanes, 64)), dim3(64), 0, st, h->meta, h->L, 2 * h->lanes, h->rep,
-                       h->twin ? 1 : 0, h->dropped, (long long)(((h->i - 1) / h->N) * h->N), h->skip_dead);
+                       h->twin ? 1 : 0, h->dropped, (long long)(((h->i - 1) / h->N) * h->N), h->skip_dead, h->now_dev,
+                       (long long)h->i);
+  else
+    hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
   if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
                      (long)n2 * n2, n2, n2, d, S, 1.0, st, h->rep)))
     return rc;
