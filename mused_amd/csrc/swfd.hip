@@ -191,21 +191,22 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
   // ---- expiry, shrink, keep / dump plan: all threads (round 2; the same decisions, in the same order, as the serial
   // form: timestamps in the ring ascend from its head, the j-th dump of this rotation lands (head + count + j) mod cap
   // whatever is evicted meanwhile, and at most count old entries are evicted because a rotation dumps <= l = cap / 2) ----
-  __shared__ int s_scan[1024];
-  __shared__ int s_tot[4];
+  __shared__ int s_part[16];      // per-wave partial counts
+  __shared__ int s_wcnt[3][4];    // per-wave totals of keep / dump / near among the l <= 256 directions (waves 0 .. 3)
   const int head0 = meta[s * 4 + 1], cnt0 = meta[s * 4 + 2];
   long long* q = qt + (long)s * cap;
-  // (a) expired snapshots: a prefix of the ring
+  const int wv = t >> 6, ln = t & 63;
+  // (a) expired snapshots: a prefix of the ring.  (Round 4: wave ballots / one exchange through LDS instead of workgroup-wide
+  // scans -- the three prefix counts and this sum cost ~70 barriers of a 16-wave workgroup, most of the kernel's time.)
   int expired = 0;
   for (int k = t; k < cnt0; k += 1024) expired += (q[(head0 + k) % cap] + N <= now) ? 1 : 0;
-  s_scan[t] = expired;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) expired += __shfl_xor(expired, o);
+  if (ln == 0) s_part[wv] = expired;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (t < o) s_scan[t] += s_scan[t + o];
-    __syncthreads();
-  }
-  const int nexp = s_scan[0];
-  __syncthreads();
+  int nexp = 0;
+#pragma unroll
+  for (int ww = 0; ww < 16; ++ww) nexp += s_part[ww];
   const int head1 = (head0 + nexp) % cap, cnt1 = cnt0 - nexp;
   // (b) per direction: shrunk energy, keep / dump
   const double l0 = lam[order[0]];
@@ -226,25 +227,28 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
     }
     scale[t] = sc;
   }
-  // (c) positions: exclusive prefix counts of keeps and of dumps over the directions in order
-  auto block_count = [&](int flag, int& total) -> int {  // exclusive prefix of `flag` over threads 0 .. 1023
-    s_scan[t] = flag;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int v = (t >= o) ? s_scan[t - o] : 0;
-      __syncthreads();
-      s_scan[t] += v;
-      __syncthreads();
-    }
-    total = s_scan[1023];
-    const int ex = s_scan[t] - flag;
-    __syncthreads();
-    return ex;
-  };
+  // (c) positions: exclusive prefix counts of keeps and of dumps over the directions in order (directions live in the
+  //     first l / 64 <= 4 waves: ballots inside a wave, the waves' totals through LDS)
+  const unsigned long long mk = __ballot(kind == 1), md = __ballot(kind == 2), mn = __ballot(near != 0);
+  const unsigned long long below = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
+  if (ln == 0 && wv < 4) {
+    s_wcnt[0][wv] = __popcll(mk);
+    s_wcnt[1][wv] = __popcll(md);
+    s_wcnt[2][wv] = __popcll(mn);
+  }
+  __syncthreads();
+  int kpos = __popcll(mk & below), dpos = __popcll(md & below);
   int nk = 0, nd = 0, nnear = 0;
-  const int kpos = block_count(kind == 1 ? 1 : 0, nk);
-  const int dpos = block_count(kind == 2 ? 1 : 0, nd);
-  (void)block_count(near, nnear);
+#pragma unroll
+  for (int ww = 0; ww < 4; ++ww) {
+    if (ww < wv) {
+      kpos += s_wcnt[0][ww];
+      dpos += s_wcnt[1][ww];
+    }
+    nk += s_wcnt[0][ww];
+    nd += s_wcnt[1][ww];
+    nnear += s_wcnt[2][ww];
+  }
   const int nevict = (cnt1 + nd > cap) ? (cnt1 + nd - cap) : 0;  // <= cnt1
   // the newest evicted timestamp (read before the new stamps overwrite the ring)
   if (t == 0) {
@@ -254,7 +258,6 @@ __global__ __launch_bounds__(1024) void swfd_decide_kernel(const double* __restr
       drop = ts > drop ? ts : drop;
     }
     dropped[s] = drop;
-    s_tot[0] = 0;
   }
   __syncthreads();
   if (t < ell) {
