@@ -36,6 +36,24 @@ def windows_with_halo(n_windows: int, world_size: int, rank: int):
     return (max(b0 - 1, 0), b0, b1)
 
 
+def lane_schedule(n_windows: int, lanes: int):
+    """Lock-step schedule of `lanes` contiguous blocks of a stream of n_windows windows, each preceded by its halo window:
+    a list over lock-steps of per-lane (window index, owned) pairs.  Step 0 is the halo step (window b0 - 1 of every block;
+    -1 = "a window of empty rows": the block that starts the stream); a lane whose block is shorter than the longest one
+    repeats its last window with owned = False (its results are discarded).  Every window is owned exactly once."""
+    blocks = [block_partition(n_windows, lanes, p) for p in range(lanes)]
+    steps = 1 + max(b1 - b0 for b0, b1 in blocks)
+    out = []
+    for t in range(steps):
+        row = []
+        for b0, b1 in blocks:
+            idx = b0 - 1 + t
+            own = t >= 1 and idx < b1
+            row.append((min(idx, b1 - 1), own))
+        out.append(row)
+    return out
+
+
 def broadcast_scalar(value, src: int = 0, device=None) -> float:
     """R of main.py:61 from the owner of window 0 to every rank."""
     import torch

@@ -596,20 +596,13 @@ class SwfdmcLanes:
         window.  Returns all_clusters in stream order (the concatenated matched labels)."""
         from . import distributed as mdist
 
-        K, Bn = len(windows), self.lanes
-        blocks = [mdist.block_partition(K, Bn, p) for p in range(Bn)]
-        steps = 1 + max(b1 - b0 for b0, b1 in blocks)
-        for t in range(steps):
-            mods, labs, trig, want = [], [], [], []
-            for b0, b1 in blocks:
-                idx = b0 - 1 + t                                 # t = 0: the halo window
-                own = t >= 1 and idx < b1
-                idx = min(idx, b1 - 1)                           # a shorter lane repeats its last window (results unused)
-                mods.append(windows[idx] if idx >= 0 else None)
-                labs.append(labels[idx] if idx >= 0 else None)
-                trig.append(idx)
-                want.append(own)
-            self.step(mods, labs, trig, want)
+        K = len(windows)
+        if K < self.lanes:
+            raise ValueError(f"{self.lanes} lanes need at least as many windows (got {K})")
+        for row in mdist.lane_schedule(K, self.lanes):
+            mods = [windows[i] if i >= 0 else None for i, _ in row]
+            labs = [labels[i] if i >= 0 else None for i, _ in row]
+            self.step(mods, labs, [i for i, _ in row], [own for _, own in row])
         self.pipe.flush()
         self.sk.check()
         raw = {tr["trigger"]: tr["raw"] for tr in self.pipe.trace}

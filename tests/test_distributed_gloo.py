@@ -109,3 +109,22 @@ def test_block_partition_covers_everything():
                 f, o, e = md.windows_with_halo(n_win, world, r)
                 assert f == max(b0 - 1, 0) and o == b0 and e == b1
             assert seen == list(range(n_win))
+
+
+@pytest.mark.parametrize("n_windows,lanes", [(3, 2), (3, 3), (20, 12), (24, 12), (7, 1), (5, 5), (16, 8)])
+def test_lane_schedule_owns_every_window_once_behind_its_halo(n_windows, lanes):
+    """The lock-step layout of SwfdmcLanes / bench.py --workload swfdmc: contiguous blocks, every block's first step is the
+    window before it (-1 = empty rows at the stream start), every window owned exactly once and in stream order per lane."""
+    from mused_amd.distributed import block_partition, lane_schedule
+
+    sched = lane_schedule(n_windows, lanes)
+    owned = sorted(i for row in sched for i, own in row if own)
+    assert owned == list(range(n_windows))
+    for p in range(lanes):
+        b0, b1 = block_partition(n_windows, lanes, p)
+        col = [row[p] for row in sched]
+        assert col[0] == (b0 - 1 if b0 > 0 else -1, False) or b1 == b0   # the halo step
+        mine = [i for i, own in col if own]
+        assert mine == list(range(b0, b1))                               # in order, contiguous
+        fed = [i for i, _ in col]
+        assert all(b - a in (0, 1) for a, b in zip(fed, fed[1:]))         # the sketch sees consecutive windows (or a repeat at the end)
