@@ -252,54 +252,6 @@ struct TrdDebug {
 };
 
 // ================= kernel A: tridiagonalisation (one workgroup = one CU per matrix) =================
-// ---- triangular factors of the blocked reflectors (the tail of kernel A; a kernel of its own until round 4) ---------------
-// Reflectors k0 .. k0 + 15 (k0 = 16 kb) as one block:  H_k0 ... H_k0+15 = I - V T V^T  with T upper triangular (LAPACK dlarft,
-// forward / columnwise):  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i).  One wave per block: V^T V by 64 MFMAs
-// (both operands of an instruction are the same register: lane (kq, li) holds V[row 4 s + kq][reflector li]), then the
-// 16 columns of T one after the other, row i on lane i.  Gs / Ts: 2 x 16 x 17 doubles of LDS private to the wave (LDS
-// operations of one wave complete in order: no workgroup barrier).
-__device__ __forceinline__ void trd_t_block(const double* __restrict__ Hs, const double* __restrict__ tau_lds,
-                                            double* __restrict__ Tout, const int kb, const int l, double* __restrict__ wl) {
-  double (*Gs)[17] = reinterpret_cast<double (*)[17]>(wl);
-  double (*Ts)[17] = reinterpret_cast<double (*)[17]>(wl + 16 * 17);
-  const int kq = l >> 4, li = l & 15;
-  const int kr = 16 * kb + li;
-  const double* vrow = Hs + (long)(kr <= TN - 3 ? kr : 0) * TN;
-  const bool okr = kr <= TN - 3;
-  v4f64 Ga = {0.0, 0.0, 0.0, 0.0}, Gb = {0.0, 0.0, 0.0, 0.0};
-  const int s_lo = (16 * kb) >> 2;  // rows below 16 kb hold no entry of these reflectors
-  for (int s4 = s_lo; s4 < TN / 4; s4 += 2) {
-    const double a0 = okr ? vrow[4 * s4 + kq] : 0.0;
-    const double a1 = okr ? vrow[4 * s4 + 4 + kq] : 0.0;
-    Ga = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Ga, 0, 0, 0);
-    Gb = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Gb, 0, 0, 0);
-  }
-  Ga += Gb;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    Gs[kq + 4 * r][li] = Ga[r];
-    Ts[kq + 4 * r][li] = 0.0;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (l < 16) {  // row i = l of T, column after column (column c only needs the columns before it)
-    for (int c = 0; c < 16; ++c) {
-      const int kc = 16 * kb + c;
-      const double tau = kc <= TN - 3 ? tau_lds[kc] : 0.0;
-      double v = 0.0;
-      if (l == c) v = tau;
-      else if (l < c) {
-        double acc = 0.0;
-        for (int b2 = l; b2 < c; ++b2) acc = fma(Ts[l][b2], Gs[b2][c], acc);
-        v = -tau * acc;
-      }
-      Ts[l][c] = v;  // (only this lane reads row l)
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int r = 0; r < 4; ++r) Tout[kb * 256 + (kq + 4 * r) * 16 + li] = Ts[kq + 4 * r][li];
-}
-
 // EMB = false: order 256 exactly (off = 0, ldn = 256: constant addressing, every step runs); true: an embedded order.
 template <bool EMB>
 __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
@@ -368,11 +320,57 @@ __global__ __launch_bounds__(TNT, 1) void trd_a_kernel(const double* __restrict_
     wsm[W_TG + TN + t] = sm[L_E + t];
     wsm[W_TG + 2 * TN + t] = sm[L_TAU + t];
   }
-  // the triangular factors of the 16 blocks of reflectors, two blocks per wave (the Householder vectors this workgroup wrote
-  // are visible to it behind the barrier above); blocks of identity reflectors of an embedded order are skipped (kernel D
-  // skips them too)
-  for (int kb = 2 * w; kb < 2 * w + 2; ++kb)
-    if (16 * kb + 15 >= off) trd_t_block(Hs, sm + L_TAU, wsm + W_TM, kb, l, S + w * (2 * 16 * 17));
+}
+
+// ================= kernel T: triangular factors of the blocked reflectors =================
+// Reflectors k0 .. k0 + 15 (k0 = 16 kb) as one block:  H_k0 ... H_k0+15 = I - V T V^T  with T upper triangular (LAPACK dlarft,
+// forward / columnwise):  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i).  One wave per block: V^T V by 64 MFMAs
+// (both operands of an instruction are the same register: lane (kq, li) holds V[row 4 s + kq][reflector li]), then the
+// 16 columns of T one after the other, row i on lane i.
+__global__ __launch_bounds__(64) void trd_t_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
+  __shared__ double Gs[16][17];
+  __shared__ double Ts[16][17];
+  const int bm = blockIdx.x >> 4, kb = blockIdx.x & 15;
+  if (rep && rep[bm] != bm) return;
+  if (16 * kb + 15 < sh.off) return;  // identity reflectors of an embedded order: kernel D skips the block as well
+  double* wsm = ws + (long)bm * W_PER;
+  const double* Hs = wsm + W_HS;
+  const int l = threadIdx.x, kq = l >> 4, li = l & 15;
+  const int kr = 16 * kb + li;
+  const double* vrow = Hs + (long)(kr <= TN - 3 ? kr : 0) * TN;
+  const bool okr = kr <= TN - 3;
+  v4f64 Ga = {0.0, 0.0, 0.0, 0.0}, Gb = {0.0, 0.0, 0.0, 0.0};
+  const int s_lo = (16 * kb) >> 2;  // rows below 16 kb hold no entry of these reflectors
+  for (int s4 = s_lo; s4 < TN / 4; s4 += 2) {
+    const double a0 = okr ? vrow[4 * s4 + kq] : 0.0;
+    const double a1 = okr ? vrow[4 * s4 + 4 + kq] : 0.0;
+    Ga = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Ga, 0, 0, 0);
+    Gb = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Gb, 0, 0, 0);
+  }
+  Ga += Gb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Gs[kq + 4 * r][li] = Ga[r];
+    Ts[kq + 4 * r][li] = 0.0;
+  }
+  __syncthreads();
+  if (l < 16) {  // row i = l of T, column after column (column c only needs the columns before it)
+    for (int c = 0; c < 16; ++c) {
+      const int kc = 16 * kb + c;
+      const double tau = kc <= TN - 3 ? wsm[W_TG + 2 * TN + kc] : 0.0;
+      double v = 0.0;
+      if (l == c) v = tau;
+      else if (l < c) {
+        double acc = 0.0;
+        for (int b2 = l; b2 < c; ++b2) acc = fma(Ts[l][b2], Gs[b2][c], acc);
+        v = -tau * acc;
+      }
+      Ts[l][c] = v;  // (only this lane reads row l)
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wsm[W_TM + kb * 256 + (kq + 4 * r) * 16 + li] = Ts[kq + 4 * r][li];
 }
 
 // ================= kernel D: certificate, then V = Q Z on the matrix cores, columns written as lam_j v_j =================
@@ -556,7 +554,7 @@ namespace mused {
 
 size_t trd_workspace_doubles(int batch) { return (size_t)batch * (size_t)W_PER; }
 
-constexpr int L_A_TOTAL = L_S + 8 * 2 * 16 * 17;   // kernel A: persistent part + its scratch (2314 for the steps, 8 x 544 for the T factors)
+constexpr int L_A_TOTAL = L_S + 2314;            // kernel A: persistent part + its scratch
 constexpr int L_DM_TOTAL = L_S + DM_TOTAL;       // kernel D
 constexpr int C_LDS = trd_c_lds_doubles<L256, 32>();        // kernel C: T, exchange, the pivot sequences of 32 vectors
 
@@ -578,7 +576,7 @@ bool trd_supports(int n, int ldn, int need) { return n >= 2 && n <= TN && ldn >=
 // done[b] = 1 -> columns 0 .. min(n, nvec) - 1 of matrix b hold lam_j v_j for its largest eigenvalues (descending; nvec = `need`
 // rounded up to a multiple of 32), every other entry zeros; done[b] = 0 -> untouched (certificate failed: solve it with the
 // Jacobi).  `need`: how many leading pairs the caller reads; cert_all: see TrdShape.  ws: trd_workspace_doubles(batch)
-// doubles.  Four launches on `st` (A with the triangular factors in its tail, B, C, D).
+// doubles.  Five launches on `st`.
 int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
               hipStream_t st, long long* dbg_clk, unsigned long long* work, hipEvent_t after_a, double* lam_out) {
   MUSED_REQUIRE(trd_supports(n, ldn, need), "trd_solve: unsupported shape (n=%d, ld=%d, need=%d)", n, ldn, need);
@@ -595,6 +593,7 @@ int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, co
   if (batch <= 64) hipLaunchKernelGGL((trd_b_kernel<128, L256>), dim3(nch * batch), dim3(128), 0, st, rep, ws, sh);
   else hipLaunchKernelGGL((trd_b_kernel<512, L256>), dim3(batch), dim3(512), 0, st, rep, ws, sh);
   hipLaunchKernelGGL((trd_c_kernel<L256, 32>), dim3(nch * batch), dim3(128), sizeof(double) * C_LDS, st, rep, ws, sh);
+  hipLaunchKernelGGL(trd_t_kernel, dim3(16 * batch), dim3(64), 0, st, rep, ws, sh);
   hipLaunchKernelGGL(trd_d_kernel, dim3(batch), dim3(TNT), sizeof(double) * L_DM_TOTAL, st, Gc, rep, done, ws, dbg, sh, lam_out);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
