@@ -197,7 +197,7 @@ int mused_swfd_levels(void* handle);
  * returns summed ms, number of osj_round_kernel launches covered, bytes one launch streams (HOST outputs) */
 int mused_swfd_profile(void* handle, int on);
 int mused_swfd_profile_read(void* handle, double* total_ms, long* launches, double* bytes_per_launch);
-/* the same for sketches whose rotations run a direct eigensolver (csrc/trd.hip: orders 2 l <= 256; csrc/trdx.hip: 320 .. 512): ms of the solver-chain launches (trd_a .. trd_d), their
+/* the same for sketches whose rotations run a direct eigensolver (csrc/trd.hip: orders 2 l <= 256; csrc/trdx.hip: 320 .. 1024): ms of the solver-chain launches (trd_a .. trd_d), their
  * number, matrices they solved; *direct = 0 -> the rotations run the Jacobi, use mused_swfd_profile_read (HOST outputs) */
 int mused_swfd_profile_read_direct(void* handle, double* total_ms, long* launches, double* matrices_solved, int* direct,
                                    double* tridiag_ms /* may be NULL: the share of total_ms spent in trd_a_kernel */);

@@ -44,10 +44,10 @@ struct EigPlan {
   unsigned qcap;
   struct OsjqCtl* qctl;
   // direct solver for the leading pairs only: runs first, the Jacobi then takes the matrices it rejected.
-  // 1: orders <= 256 (trd.hip; fallback = the persistent queue Jacobi); 2: orders 320 .. 512 (trdx.hip; fallback = the sweep graph)
+  // 1: orders <= 256 (trd.hip; fallback = the persistent queue Jacobi); 2: orders 320 .. 1024 (trdx.hip; fallback = the sweep graph)
   int trd;
   const int* jrep;     // what the Jacobi's launch-per-round kernels test (matrix b runs when jrep[b] == b): rep, or -- behind the
-                       // direct solver of orders 320 .. 512 (trdx.hip) -- the per-solve list of the matrices it rejected
+                       // direct solver of orders 320 .. 1024 (trdx.hip) -- the per-solve list of the matrices it rejected
   int *trdx_act, *trdx_jrep;  // trdx: matrices that passed (act[b] == b) / that the Jacobi must solve (jrep[b] == b)
   int* trdx_nrej;             // trdx: device count of the matrices the last solve rejected
   int* trdx_nrej_host;        // ... its pinned host copy: the Jacobi's sweep graph (hundreds of launches that would find nothing
@@ -1206,9 +1206,9 @@ int eig_plan_create(int n, int batch, int sweeps, bool own_graph, EigPlan** out,
         if (rc_t) return rc_t;
         MUSED_CHECK_HIP(hipMalloc(&p->trd_ws, sizeof(double) * trd_workspace_doubles(batch)));
         MUSED_CHECK_HIP(hipMalloc(&p->trd_done, sizeof(int) * (size_t)batch));
-      } else if (p->trd_need > 0 && p->wavek && trdx_supports(p->ldn, p->trd_need) &&
+      } else if (p->trd_need > 0 && trdx_supports(p->ldn, p->trd_need) &&
                  !(getenv("MUSED_EIG_TRD") && getenv("MUSED_EIG_TRD")[0] == '0')) {
-        // orders 320 .. 512: blocked direct solver; the sweep graph below runs on the matrices it rejects (jrep)
+        // orders 320 .. 1024: blocked direct solver; the sweep graph below runs on the matrices it rejects (jrep)
         p->trd = 2;
         int rc_t = trdx_prepare(p->ldn);
         if (rc_t) return rc_t;

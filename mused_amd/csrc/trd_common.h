@@ -1,4 +1,4 @@
-// Pieces the two direct eigensolvers share (trd.hip: orders <= 256, matrix in registers; trdx.hip: orders 320 .. 512, blocked,
+// Pieces the two direct eigensolvers share (trd.hip: orders <= 256, matrix in registers; trdx.hip: orders 320 .. 1024, blocked,
 // matrix streamed): the division-free Sturm count, kernel B (eigenvalues of T by multisection), kernel C (eigenvectors of T
 // by twisted factorisation) -- templated on the order through a compile-time workspace layout -- and the certificate levels.
 #pragma once
@@ -217,14 +217,14 @@ __global__ __launch_bounds__(NTB) void trd_b_kernel(const int* __restrict__ rep,
 // Two waves: wave 0 runs the forward pivots and the part of each vector above its twist index, wave 1 the backward pivots
 // and the part below (two dependent chains of TNX - 1 divisions side by side); lane c < VPW of either wave = vector
 // cq * VPW + c.  The pivot sequences of the VPW vectors stay in LDS ([i][vector], 2 x TNX x VPW doubles: one workgroup per
-// CU; VPW = 32 at order 256, 16 up to order 512); every stretch of a dependent chain is preceded by its batch of loads.
+// CU; VPW = 32 at order 256, 16 up to order 512, 8 up to order 1024); every stretch of a dependent chain is preceded by its batch of loads.
 template <typename LY, int VPW>
 constexpr int trd_c_lds_doubles() { return 2 * LY::TNX + LY::TNX + 4 * VPW + 2 * LY::TNX * VPW; }
 
 template <typename LY, int VPW>
 __global__ __launch_bounds__(128) void trd_c_kernel(const int* __restrict__ rep, double* __restrict__ ws, const TrdShape sh) {
   constexpr int TNX = LY::TNX, TMX = LY::TMX;
-  static_assert(TNX % 32 == 0 && (VPW == 16 || VPW == 32), "trd_c_kernel: unsupported shape");
+  static_assert(TNX % 32 == 0 && (VPW == 8 || VPW == 16 || VPW == 32), "trd_c_kernel: unsupported shape");
   extern __shared__ __attribute__((aligned(16))) double smc[];  // trd_c_lds_doubles<LY, VPW>() doubles
   double2* dd2 = reinterpret_cast<double2*>(smc);  // [TNX]
   double* es = smc + 2 * TNX;                      // [TNX]

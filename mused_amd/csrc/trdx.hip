@@ -1,13 +1,14 @@
-// Direct symmetric eigensolver for the Gram matrices of orders 320 .. 512 (round 4): the FD rotation at l = 256 (BASELINE
-// config 3: order 2 l = 512), the sketch query at l = 128 (order 3 l = 384, 4 l = 512 with rows pending).  Same chain as
+// Direct symmetric eigensolver for the Gram matrices of orders 320 .. 1024 (round 4): the FD rotation at l = 256 (BASELINE
+// config 3: order 2 l = 512), the sketch query at l = 128 (order 3 l = 384, 4 l = 512 with rows pending) and at l = 256 (order
+// 768 / 1024).  Same chain as
 // trd.hip -- tridiagonalisation, the leading eigenvalues by multisection, their vectors by twisted factorisation,
 // back-transformation, certificate with the one-sided Jacobi (eig.hip) as fallback -- but a matrix of this order (1 - 2 MB)
 // is not register resident on one CU, and splitting it over several CUs would put a grid-wide exchange through L2 behind
 // every one of its n columns.  So ONE workgroup per matrix keeps the LAPACK dsytrd structure instead:
 //
-//   A  blocked Householder tridiagonalisation (dlatrd panels of 16 columns, lower variant).  Inside a panel the trailing
-//      matrix is NOT updated: column j is brought up to date from the panel's V / W (kept in registers, one matrix row per
-//      thread), y = A v STREAMS the lower triangle of the panel-start matrix from L2 / Infinity Cache -- symmetric: every
+//   A  blocked Householder tridiagonalisation (dlatrd panels of 16 columns, lower variant; 8 columns above order 512).  Inside a
+//      panel the trailing matrix is NOT updated: column j is brought up to date from the panel's V / W (kept in registers, one
+//      matrix row per thread, two above order 512), y = A v STREAMS the lower triangle of the panel-start matrix from L2 / Infinity Cache -- symmetric: every
 //      128 x 32 tile is read once and serves the row part and the column part of the product -- and the rank-32 update
 //      A -= V W^T + W V^T of a finished panel runs on the matrix cores (v_mfma_f64_16x16x4, operands staged in LDS).
 //      Algorithmic bytes: n^3 / 6 doubles of symv reads per matrix (179 MB at n = 512): the kernel is bound by what one CU
@@ -24,7 +25,6 @@
 
 namespace mused {
 
-constexpr int XNB = 16;  // panel width of the blocked tridiagonalisation
 constexpr int XRB = 64;  // reflectors per compact-WY block of the back-transformation
 
 template <int NX>
@@ -95,19 +95,37 @@ __device__ __forceinline__ double wave_treduce16(double (&r)[16], const int l, i
   return r[0];
 }
 
-// ================= kernel A: blocked tridiagonalisation, one workgroup (NX threads: thread t <-> matrix row t) per matrix ======
+// ================= kernel A: blocked tridiagonalisation, one workgroup per matrix =================
+// Orders <= 512: NX threads, thread t <-> matrix row t, panels of 16 columns.  Orders 640 .. 1024: NX / 2 threads, thread t <->
+// rows t and t + NX / 2, panels of 8 columns (either way the panel's V and W rows stay in registers, 2 x 16 doubles per thread, and
+// the staged panel fits the 160 KB of LDS beside the waves' partial sums).
 // LDS (doubles): vs[NX] | red[NW][34] | rowv[16] roww[16] misc[8] gsum[34] | U: ypart[NW][NX] during the column steps,
-// Vs[NX][17] Ws[NX][17] during the update of a finished panel.
+// Vs[NX][NB + 1] Ws[NX][NB + 1] during the update of a finished panel.
+template <int NX>
+struct XA {
+  static constexpr int RPT = NX > 512 ? 2 : 1;  // matrix rows per thread
+  static constexpr int NT = NX / RPT;           // threads
+  static constexpr int NB = NX > 512 ? 8 : 16;  // panel width
+  static constexpr int NW = NT / 64;
+  static constexpr int PITCH = NB + 1;
+  static constexpr int VPW = NX > 512 ? 8 : 16;  // vectors per workgroup of kernel C (their pivot sequences fill its LDS)
+  static constexpr int U_DOUBLES = (NW * NX > 2 * NX * PITCH) ? NW * NX : 2 * NX * PITCH;
+  static constexpr int LDS_DOUBLES = NX + NW * 34 + 40 + 34 + U_DOUBLES;
+  static_assert(NT % 64 == 0 && NT <= 512 && LDS_DOUBLES * 8 <= 160 * 1024, "trdx: unsupported order");
+};
+
 template <int NX>
 constexpr int trdx_a_lds_doubles() {
-  return NX + (NX / 64) * 34 + 40 + 34 + 2 * NX * 17;
+  return XA<NX>::LDS_DOUBLES;
 }
 
 template <int NX>
-__global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
-                                                    double* __restrict__ ws, long long* __restrict__ prof) {
+__global__ __launch_bounds__(XA<NX>::NT) void trdx_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
+                                                            double* __restrict__ ws, long long* __restrict__ prof) {
   using LY = LX<NX>;
-  constexpr int NW = NX / 64, NS = NX / 16, NT128 = (NX + 127) / 128;
+  using K = XA<NX>;
+  constexpr int RPT = K::RPT, NT = K::NT, NB = K::NB, NW = K::NW, PITCH = K::PITCH;
+  constexpr int NS = NX / 16, NT128 = (NX + 127) / 128;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
   if (rep && rep[bm] != bm) return;
@@ -125,13 +143,15 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
   double* ypart = U + w * NX;  // this wave's partial sums of y = A v
   {  // working copy (a rejected matrix goes to the Jacobi untouched)
     const double* G = Gc + (long)bm * NX * NX;
-    for (int e = t; e < NX * NX / 2; e += NX)
+    for (int e = t; e < NX * NX / 2; e += NT)
       reinterpret_cast<double2*>(A)[e] = reinterpret_cast<const double2*>(G)[e];
   }
   __syncthreads();
-  double Vr[XNB], Wr[XNB];
+  double Vr[RPT][NB], Wr[RPT][NB];  // rows t + h NT of the panel's V and W
 #pragma unroll
-  for (int c = 0; c < XNB; ++c) { Vr[c] = 0.0; Wr[c] = 0.0; }
+  for (int h = 0; h < RPT; ++h)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { Vr[h][c] = 0.0; Wr[h][c] = 0.0; }
   const int kq = l >> 4, li = l & 15;
   // diagnostic (prof != nullptr): s_memtime ticks of thread 0 in [column + Householder | symv | reductions + w | panel update]
   long long pacc[4] = {0, 0, 0, 0}, plast = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -142,29 +162,48 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
       plast = now;
     }
   };
-  for (int j0 = 0; j0 < NX; j0 += XNB) {
-    double anext = A[(long)j0 * NX + t];  // column j0 of the matrix as the last panel update left it
-    for (int i = 0; i < XNB; ++i) {
+  for (int j0 = 0; j0 < NX; j0 += NB) {
+    double anext[RPT];  // column j0 of the matrix as the last panel update left it
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) anext[h] = A[(long)j0 * NX + t + h * NT];
+    for (int i = 0; i < NB; ++i) {
       const int j = j0 + i;
       // (S1) row j of the panel's V, W -> LDS; column j of the panel-start matrix (fetched a column ahead: the matrix does
       //      not change inside a panel, and the load's latency would otherwise sit in front of every column)
-      if (t == j) {
+      double a[RPT];
 #pragma unroll
-        for (int c = 0; c < XNB; ++c) { rowv[c] = Vr[c]; roww[c] = Wr[c]; }
+      for (int h = 0; h < RPT; ++h) {
+        const int row = t + h * NT;
+        if (row == j) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) { rowv[c] = Vr[h][c]; roww[c] = Wr[h][c]; }
+        }
+        a[h] = (row >= j) ? anext[h] : 0.0;
       }
-      double a = (t >= j) ? anext : 0.0;
-      if (i + 1 < XNB) anext = A[(long)(j + 1) * NX + t];
+      if (i + 1 < NB) {
+#pragma unroll
+        for (int h = 0; h < RPT; ++h) anext[h] = A[(long)(j + 1) * NX + t + h * NT];
+      }
       lds_barrier();
       // (S2) bring it up to date: a -= V W[j]^T + W V[j]^T over the panel's earlier columns
 #pragma unroll
-      for (int c = 0; c < XNB; ++c)
-        if (c < i) a = fma(-Vr[c], roww[c], fma(-Wr[c], rowv[c], a));
-      if (t == j) wsm[LY::W_TG + j] = a;  // d_j
+      for (int c = 0; c < NB; ++c)
+        if (c < i) {
+          const double rv = rowv[c], rw = roww[c];
+#pragma unroll
+          for (int h = 0; h < RPT; ++h) a[h] = fma(-Vr[h][c], rw, fma(-Wr[h][c], rv, a[h]));
+        }
       {
-        double sq = (t > j + 1) ? a * a : 0.0;
+        double sq = 0.0;
+#pragma unroll
+        for (int h = 0; h < RPT; ++h) {
+          const int row = t + h * NT;
+          if (row == j) wsm[LY::W_TG + j] = a[h];  // d_j
+          if (row == j + 1) misc[0] = a[h];
+          sq += (row > j + 1) ? a[h] * a[h] : 0.0;
+        }
         sq = wave_allsum(sq);
         if (l == 0) red[w] = sq;
-        if (t == j + 1) misc[0] = a;
       }
       lds_barrier();
       // (S3) Householder vector (dlarfg), every thread for itself: beta = -sign(x0) |x|, tau = (beta - x0) / beta,
@@ -175,31 +214,38 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
       const double x0 = (j + 1 < NX) ? misc[0] : 0.0;
       double tau = 0.0, beta = x0, scale = 0.0;
       if (sqs > 1e-280) {
-        const double h = fma(x0, x0, sqs);
-        double rs = __builtin_amdgcn_rsq(h);
-        rs = rs * fma(-0.5 * h, rs * rs, 1.5);
-        rs = rs * fma(-0.5 * h, rs * rs, 1.5);
-        const double nrm = h * rs;
+        const double hh = fma(x0, x0, sqs);
+        double rs = __builtin_amdgcn_rsq(hh);
+        rs = rs * fma(-0.5 * hh, rs * rs, 1.5);
+        rs = rs * fma(-0.5 * hh, rs * rs, 1.5);
+        const double nrm = hh * rs;
         beta = x0 >= 0.0 ? -nrm : nrm;
         tau = (beta - x0) * trd_rcp(beta);
         scale = trd_rcp(x0 - beta);
       }
-      const double v = (tau != 0.0) ? (t > j + 1 ? a * scale : (t == j + 1 ? 1.0 : 0.0)) : 0.0;
-      vs[t] = v;
-      Hs[(long)j * NX + t] = v;
+      double v[RPT];
 #pragma unroll
-      for (int c = 0; c < XNB; ++c) Vr[c] = (c == i) ? v : Vr[c];
+      for (int h = 0; h < RPT; ++h) {
+        const int row = t + h * NT;
+        v[h] = (tau != 0.0) ? (row > j + 1 ? a[h] * scale : (row == j + 1 ? 1.0 : 0.0)) : 0.0;
+        vs[row] = v[h];
+        Hs[(long)j * NX + row] = v[h];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Vr[h][c] = (c == i) ? v[h] : Vr[h][c];
+      }
       if (t == 0) {
         wsm[LY::W_TG + NX + j] = (j + 1 < NX) ? beta : 0.0;  // e_j
         wsm[LY::W_TG + 2 * NX + j] = tau;
       }
 #pragma unroll
-      for (int e = 0; e < NW; ++e) ypart[l + 64 * e] = 0.0;
+      for (int e = 0; e < NX / 64; ++e) ypart[l + 64 * e] = 0.0;
       lds_barrier();
       ptick(0);
       if (tau == 0.0) {  // H = I (uniform: every thread computed the same scalars from the same data)
 #pragma unroll
-        for (int c = 0; c < XNB; ++c) Wr[c] = (c == i) ? 0.0 : Wr[c];
+        for (int h = 0; h < RPT; ++h)
+#pragma unroll
+          for (int c = 0; c < NB; ++c) Wr[h][c] = (c == i) ? 0.0 : Wr[h][c];
         continue;
       }
       // (S4) y = A v over the lower triangle of the panel-start matrix, rows / columns > j (v is zero above).  Column
@@ -265,20 +311,35 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
       // (S5) y0 = sum of the waves' parts;  G1 = W^T v,  G2 = V^T v,  S = v . y0  reduced over the workgroup: per wave by a
       //      transposing reduction, over the waves by the first 33 threads (every thread summing the 8 x 33 partials itself
       //      cost more LDS cycles than the barrier this takes)
-      double y0 = 0.0;
+      double y0[RPT];
 #pragma unroll
-      for (int ww = 0; ww < NW; ++ww) y0 += U[ww * NX + t];
+      for (int h = 0; h < RPT; ++h) {
+        y0[h] = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) y0[h] += U[ww * NX + t + h * NT];
+      }
       {
         double g[32];
 #pragma unroll
-        for (int c = 0; c < XNB; ++c) {
-          g[c] = Wr[c] * v;
-          g[16 + c] = Vr[c] * v;
+        for (int c = 0; c < 16; ++c) {
+          double gw = 0.0, gv = 0.0;
+          if (c < NB) {
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) {
+              gw = fma(Wr[h][c < NB ? c : 0], v[h], gw);
+              gv = fma(Vr[h][c < NB ? c : 0], v[h], gv);
+            }
+          }
+          g[c] = gw;
+          g[16 + c] = gv;
         }
         int idx;
         const double gs = wave_treduce32(g, l, idx);
         if ((l & 2) == 0) red[w * 34 + idx] = gs;
-        const double ss = wave_allsum(v * y0);
+        double sv = 0.0;
+#pragma unroll
+        for (int h = 0; h < RPT; ++h) sv = fma(v[h], y0[h], sv);
+        const double ss = wave_allsum(sv);
         if (l == 0) red[w * 34 + 32] = ss;
       }
       lds_barrier();
@@ -291,54 +352,82 @@ __global__ __launch_bounds__(NX) void trdx_a_kernel(const double* __restrict__ G
       lds_barrier();
       // (S6) y = y0 - V G1 - W G2;  w = tau y - (tau^2 / 2) (v . y) v   with  v . y = S - 2 G1 . G2
       {
-        double y = y0, dot = 0.0;
+        double y[RPT], dot = 0.0;
 #pragma unroll
-        for (int c = 0; c < XNB; ++c) {
+        for (int h = 0; h < RPT; ++h) y[h] = y0[h];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
           if (c < i) {
             const double g1 = gsum[c], g2 = gsum[16 + c];
-            y = fma(-Vr[c], g1, fma(-Wr[c], g2, y));
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) y[h] = fma(-Vr[h][c], g1, fma(-Wr[h][c], g2, y[h]));
             dot = fma(g1, g2, dot);
           }
         }
         const double vy = gsum[32] - 2.0 * dot;
-        const double wv = (t > j) ? fma(tau, y, -0.5 * tau * tau * vy * v) : 0.0;
 #pragma unroll
-        for (int c = 0; c < XNB; ++c) Wr[c] = (c == i) ? wv : Wr[c];
+        for (int h = 0; h < RPT; ++h) {
+          const double wv = (t + h * NT > j) ? fma(tau, y[h], -0.5 * tau * tau * vy * v[h]) : 0.0;
+#pragma unroll
+          for (int c = 0; c < NB; ++c) Wr[h][c] = (c == i) ? wv : Wr[h][c];
+        }
       }
       ptick(2);
     }
-    // ---- the finished panel: A[r0:, r0:] -= V W^T + W V^T on the lower triangle, 16 x 16 tiles on the matrix cores ----
-    const int r0p = j0 + XNB;
+    // ---- the finished panel: A[r0:, r0:] -= V W^T + W V^T on the lower triangle, 16 x 16 tiles on the matrix cores (the tile
+    //      grid starts at the multiple of 16 at or below r0: with panels of 8 every other update also touches 8 finished rows /
+    //      columns, whose entries are only ever multiplied by the zeros of later Householder vectors) ----
+    const int r0p = j0 + NB;
     lds_barrier();  // (every wave has read ypart / red of the last column)
     double* Vs = U;
-    double* Ws = U + NX * 17;
+    double* Ws = U + NX * PITCH;
 #pragma unroll
-    for (int c = 0; c < XNB; ++c) {
-      Vs[t * 17 + c] = Vr[c];
-      Ws[t * 17 + c] = Wr[c];
-    }
+    for (int h = 0; h < RPT; ++h)
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        Vs[(t + h * NT) * PITCH + c] = Vr[h][c];
+        Ws[(t + h * NT) * PITCH + c] = Wr[h][c];
+      }
     lds_barrier();
     if (r0p < NX) {
-      const int Tt = (NX - r0p) / 16;
-      int cnt = 0;
-      for (int I = 0; I < Tt; ++I)
-        for (int J = 0; J <= I; ++J, ++cnt) {
-          if (cnt % NW != w) continue;
-          const int R = r0p + 16 * I, Cc = r0p + 16 * J;
+      // tiles q = 0 .. Tt (Tt + 1) / 2 - 1 of the lower triangle (row-wise: q = I (I + 1) / 2 + J), tile q to wave q mod NW; a wave
+      // takes four of its tiles at a time -- 16 loads in flight instead of 4: one tile at a time left this step latency bound
+      const int R0 = r0p & ~15, Tt = (NX - R0) / 16, total = Tt * (Tt + 1) / 2;
+      constexpr int TG = 4;
+      for (int q0 = w; q0 < total; q0 += NW * TG) {
+        double* tp[TG];
+        int Rr[TG], Cr[TG];
+        v4f64 acc[TG];
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {
+          const int q = (q0 + NW * g < total) ? q0 + NW * g : q0;  // (a spare slot repeats tile q0 and is not stored)
+          int I = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+          I += ((I + 1) * (I + 2) / 2 <= q) ? 1 : 0;
+          I -= (I * (I + 1) / 2 > q) ? 1 : 0;
+          const int J = q - I * (I + 1) / 2;
+          Rr[g] = R0 + 16 * I;
+          Cr[g] = R0 + 16 * J;
           // tile in the C / D layout with M = matrix column, N = matrix row: lane (kq, li), register r <-> row R + li,
           // column Cc + kq + 4 r (lanes li read / write 16 consecutive rows of a column)
-          double* tp = A + (long)(Cc + kq) * NX + R + li;
-          v4f64 acc;
+          tp[g] = A + (long)(Cr[g] + kq) * NX + Rr[g] + li;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = tp[(long)4 * r * NX];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ws[(Cc + li) * 17 + 4 * s4 + kq], Vs[(R + li) * 17 + 4 * s4 + kq], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Vs[(Cc + li) * 17 + 4 * s4 + kq], Ws[(R + li) * 17 + 4 * s4 + kq], acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tp[(long)4 * r * NX] = acc[r];
+          for (int r = 0; r < 4; ++r) acc[g][r] = tp[g][(long)4 * r * NX];
         }
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {
+#pragma unroll
+          for (int s4 = 0; s4 < NB / 4; ++s4) {
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ws[(Cr[g] + li) * PITCH + 4 * s4 + kq], Vs[(Rr[g] + li) * PITCH + 4 * s4 + kq], acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Vs[(Cr[g] + li) * PITCH + 4 * s4 + kq], Ws[(Rr[g] + li) * PITCH + 4 * s4 + kq], acc[g], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < TG; ++g)
+          if (q0 + NW * g < total) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tp[g][(long)4 * r * NX] = acc[g][r];
+          }
+      }
     }
     __syncthreads();  // the updated matrix is visible to the whole workgroup; U may be reused
     ptick(3);
@@ -501,8 +590,8 @@ static int trdx_prepare_t() {
     rc = hipFuncSetAttribute((const void*)trdx_a_kernel<NX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(sizeof(double) * trdx_a_lds_doubles<NX>()));
     if (rc == hipSuccess)
-      rc = hipFuncSetAttribute((const void*)trd_c_kernel<LY, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(double) * trd_c_lds_doubles<LY, 16>()));
+      rc = hipFuncSetAttribute((const void*)trd_c_kernel<LY, XA<NX>::VPW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * trd_c_lds_doubles<LY, XA<NX>::VPW>()));
     if (rc == hipSuccess)
       rc = hipFuncSetAttribute((const void*)trdx_larft_kernel<LY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * 2 * XRB * XRB));
@@ -516,12 +605,13 @@ static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* re
                         double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof, double* lam_out) {
   using LY = LX<NX>;
   const long per = LY::W_PER;
-  const int nvec = sh.nvec, nch32 = nvec / 32, nch16 = nvec / 16;
-  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(NX), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws, prof);
+  constexpr int VPW = XA<NX>::VPW;
+  const int nvec = sh.nvec, nch32 = nvec / 32, nchc = nvec / VPW;
+  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(XA<NX>::NT), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws, prof);
   if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));
   hipLaunchKernelGGL((trd_b_kernel<128, LY>), dim3(nch32 * batch), dim3(128), 0, st, rep, ws, sh);
-  constexpr size_t c_lds = sizeof(double) * trd_c_lds_doubles<LY, 16>();
-  hipLaunchKernelGGL((trd_c_kernel<LY, 16>), dim3(nch16 * batch), dim3(128), c_lds, st, rep, ws, sh);
+  constexpr size_t c_lds = sizeof(double) * trd_c_lds_doubles<LY, VPW>();
+  hipLaunchKernelGGL((trd_c_kernel<LY, VPW>), dim3(nchc * batch), dim3(128), c_lds, st, rep, ws, sh);
   hipLaunchKernelGGL(trdx_cert_kernel<LY>, dim3(batch), dim3(256), 0, st, rep, ws, done, act, jrep, nrej, work, sh);
   MUSED_LAUNCH_CHECK();
   int rc;
@@ -554,26 +644,34 @@ static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* re
 }
 
 bool trdx_supports(int ldn, int need) {
-  return (ldn == 320 || ldn == 384 || ldn == 448 || ldn == 512) && need >= 1 && ((need + 31) / 32) * 32 <= ldn / 2;
+  const bool order = (ldn >= 320 && ldn <= 512 && ldn % 64 == 0) || (ldn >= 640 && ldn <= 1024 && ldn % 128 == 0);
+  return order && need >= 1 && ((need + 31) / 32) * 32 <= ldn / 2;
 }
 
-size_t trdx_workspace_doubles(int ldn, int batch) {
-  switch (ldn) {
-    case 320: return (size_t)batch * LX<320>::W_PER;
-    case 384: return (size_t)batch * LX<384>::W_PER;
-    case 448: return (size_t)batch * LX<448>::W_PER;
-    default: return (size_t)batch * LX<512>::W_PER;
+// EXPR(NX) for the supported order ldn (the callers have checked trdx_supports)
+#define TRDX_DISPATCH(ldn, EXPR) \
+  switch (ldn) {                 \
+    case 320: EXPR(320); break;  \
+    case 384: EXPR(384); break;  \
+    case 448: EXPR(448); break;  \
+    case 512: EXPR(512); break;  \
+    case 640: EXPR(640); break;  \
+    case 768: EXPR(768); break;  \
+    case 896: EXPR(896); break;  \
+    default: EXPR(1024); break;  \
   }
+
+size_t trdx_workspace_doubles(int ldn, int batch) {
+#define TRDX_WS(NX) return (size_t)batch * LX<NX>::W_PER
+  TRDX_DISPATCH(ldn, TRDX_WS)
+  return 0;
 }
 
 int trdx_prepare(int ldn) {
-  switch (ldn) {
-    case 320: return trdx_prepare_t<320>();
-    case 384: return trdx_prepare_t<384>();
-    case 448: return trdx_prepare_t<448>();
-    case 512: return trdx_prepare_t<512>();
-    default: set_error("trdx_prepare: unsupported order %d", ldn); return MUSED_ERR_UNSUPPORTED;
-  }
+  MUSED_REQUIRE(trdx_supports(ldn, 1), "trdx_prepare: unsupported order %d", ldn);
+#define TRDX_PREP(NX) return trdx_prepare_t<NX>()
+  TRDX_DISPATCH(ldn, TRDX_PREP)
+  return MUSED_OK;
 }
 
 // Solves the matrices of Gc (batch x ldn x ldn column-major, symmetric, zero padded beyond the caller's order) in place:
@@ -590,12 +688,9 @@ int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const in
   sh.nvec = ((need + 31) / 32) * 32;
   sh.need = need;
   sh.cert_all = cert_all ? 1 : 0;
-  switch (ldn) {
-    case 320: return trdx_solve_t<320>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
-    case 384: return trdx_solve_t<384>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
-    case 448: return trdx_solve_t<448>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
-    default: return trdx_solve_t<512>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out);
-  }
+#define TRDX_SOLVE(NX) return trdx_solve_t<NX>(Gc, sh, batch, rep, done, act, jrep, nrej, ws, st, work, after_a, prof, lam_out)
+  TRDX_DISPATCH(ldn, TRDX_SOLVE)
+  return MUSED_OK;
 }
 
 }  // namespace mused
@@ -603,7 +698,7 @@ int trdx_solve(double* Gc, int ldn, int need, bool cert_all, int batch, const in
 using namespace mused;
 
 // Diagnostic / unit-test entry (not part of the declared ABI): the solver alone on `batch` symmetric matrices of order
-// n in {320, 384, 448, 512} (device, column-major, overwritten as trdx_solve does).  out_d / out_e: batch x n, out_lam / out_res:
+// n in {320, ..., 512 step 64; 640, ..., 1024 step 128} (device, column-major, overwritten as trdx_solve does).  out_d / out_e: batch x n, out_lam / out_res:
 // batch x n / 2 (the first `need` rounded up to 32 are formed), out_done: batch ints.
 extern "C" int mused_debug_trdx(double* G, int n, int need, int cert_all, int batch, double* out_d, double* out_e,
                                 double* out_lam, double* out_res, int* out_done, void* stream) {
@@ -619,12 +714,8 @@ extern "C" int mused_debug_trdx(double* G, int n, int need, int cert_all, int ba
   rc = trdx_solve(G, n, need, cert_all != 0, batch, nullptr, out_done, ib, ib + batch, ib + 2 * batch, ws, st, nullptr, nullptr);
   if (!rc) {
     const int nvec = ((need + 31) / 32) * 32;
-    switch (n) {
-      case 320: hipLaunchKernelGGL((trdx_export_kernel<LX<320>>), dim3(batch), dim3(320), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
-      case 384: hipLaunchKernelGGL((trdx_export_kernel<LX<384>>), dim3(batch), dim3(384), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
-      case 448: hipLaunchKernelGGL((trdx_export_kernel<LX<448>>), dim3(batch), dim3(448), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
-      default: hipLaunchKernelGGL((trdx_export_kernel<LX<512>>), dim3(batch), dim3(512), 0, st, ws, out_d, out_e, out_lam, out_res, nvec); break;
-    }
+#define TRDX_EXPORT(NX) hipLaunchKernelGGL((trdx_export_kernel<LX<NX>>), dim3(batch), dim3(NX), 0, st, ws, out_d, out_e, out_lam, out_res, nvec)
+    TRDX_DISPATCH(n, TRDX_EXPORT)
   }
   hipError_t e = hipStreamSynchronize(st);
   (void)hipFree(ws);

@@ -290,7 +290,7 @@ def test_direct_solver_exactly_rank_deficient_duplicates(n):
 
 
 def run_trdx(Gs, n, need, cert_all=0):
-    """The blocked solver of orders 320 .. 512 (csrc/trdx.hip)."""
+    """The blocked solver of orders 320 .. 1024 (csrc/trdx.hip)."""
     from mused_amd import _lib
     from mused_amd.engine import ptr, stream_ptr
 
@@ -310,13 +310,16 @@ def run_trdx(Gs, n, need, cert_all=0):
     return G.cpu().numpy(), d.cpu().numpy(), e.cpu().numpy(), lam.cpu().numpy(), res.cpu().numpy(), done.cpu().numpy()
 
 
-@pytest.mark.parametrize("n,need", [(320, 160), (384, 128), (448, 224), (512, 256), (512, 128)])
+@pytest.mark.parametrize("n,need", [(320, 160), (384, 128), (448, 224), (512, 256), (512, 128), (640, 200), (768, 256),
+                                    (896, 300), (1024, 256), (1024, 512)])
 def test_blocked_direct_solver_matches_lapack(n, need):
     """Orders 320 .. 512 (config 3's rotations at l = 256: order 512, top 256; the sketch query at l = 128: order 384 / 512,
-    top 128): blocked tridiagonalisation (the same T as the unblocked reduction, to rounding), leading eigenpairs against
+    top 128) and 640 .. 1024 (two matrix rows per thread, panels of 8; config 3's sketch query at l = 256: order 768 / 1024,
+    top 256): blocked tridiagonalisation (the same T as the unblocked reduction, to rounding), leading eigenpairs against
     LAPACK, zero columns elsewhere, same certificate."""
     ell = n // 2
-    Gs = fd_buffers("blob", 3, ell=ell, d=1024) + fd_buffers("fd", 2, ell=ell, d=700, seed=1)
+    # (d > n: a buffer of rank below its row count leaves the tail of T undetermined -- see below)
+    Gs = fd_buffers("blob", 3, ell=ell, d=max(1024, n + 256)) + fd_buffers("fd", 2, ell=ell, d=max(700, n + 100), seed=1)
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, 90))
     Gs.append(B @ B.T)                                     # rank 90: most of the spectrum zero

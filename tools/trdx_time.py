@@ -1,4 +1,4 @@
-"""Times the blocked direct eigensolver of orders 320 .. 512 (csrc/trdx.hip) alone on Gram matrices of FD rotation buffers,
+"""Times the blocked direct eigensolver of orders 320 .. 1024 (csrc/trdx.hip) alone on Gram matrices of FD rotation buffers,
 beside the one-sided Jacobi of the same order:  python tools/trdx_time.py [n:need:batch ...]"""
 import ctypes as C, os, sys
 import numpy as np, torch
