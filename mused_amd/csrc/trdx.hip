@@ -14,8 +14,9 @@
 //      Algorithmic bytes: n^3 / 6 doubles of symv reads per matrix (179 MB at n = 512): the kernel is bound by what one CU
 //      pulls from the memory system, not by flops.  All reductions have a fixed order: results do not depend on the batch.
 //   B, C  trd_common.h (the kernels of trd.hip, templated on the order).
-//   certificate, then  V = Q Z  blocked as compact-WY blocks of 64 reflectors on the batched fp64 MFMA GEMM of this
-//      library (S = V_b Z, C = T_b S, Z -= V_b^T C), triangular factors T_b by dlarft from the block Grams.
+//   certificate, then  V = Q Z  blocked as compact-WY blocks of 64 reflectors: the triangular factors T_b by dlarft from block
+//      Grams formed on the matrix cores (one workgroup per block), then one workgroup per 32 columns of Z carries its slab
+//      through all blocks in MFMA accumulator registers (S = V_b Z, C = T_b S, Z -= V_b^T C).
 //
 // The matrix is solved on a COPY (a rejected matrix goes to the Jacobi untouched), on its padded order ldn (zero rows /
 // columns add zero eigenvalues below the spectrum of a PSD matrix).
@@ -33,15 +34,12 @@ struct LX {
   static constexpr long W_A = 0;                                  // NX x NX   working copy of the matrix (column-major)
   static constexpr long W_HS = W_A + (long)NX * NX;               // NX x NX   Householder vectors (row k = v_k)
   static constexpr long W_ZG = W_HS + (long)NX * NX;              // NX x TMX  eigenvectors of T, unnormalised ([i][c])
-  static constexpr long W_ZB = W_ZG + (long)NX * TMX;             // NX x TMX  normalised, then back-transformed in place
+  static constexpr long W_ZB = W_ZG + (long)NX * TMX;             // NX x TMX  back-transformed ([i][c])
   static constexpr long W_TG = W_ZB + (long)NX * TMX;             // d, e, tau
   static constexpr long W_LG = W_TG + 3 * NX;                     // lam, 1 / |z|, residual / |T|
   static constexpr long W_MI = W_LG + 3 * TMX;                    // {|T|, pivmin, bad flag, ...}
   static constexpr long W_TF = W_MI + 16;                         // NBLK x 64 x 64 triangular factors
-  static constexpr long W_GB = W_TF + (long)NBLK * XRB * XRB;     // NBLK x 64 x 64 block Grams V_b V_b^T
-  static constexpr long W_S = W_GB + (long)NBLK * XRB * XRB;      // 64 x TMX
-  static constexpr long W_C = W_S + (long)XRB * TMX;              // 64 x TMX
-  static constexpr long W_PER = W_C + (long)XRB * TMX;
+  static constexpr long W_PER = W_TF + (long)NBLK * XRB * XRB;
   static_assert(W_PER % 2 == 0 && NX % 64 == 0, "layout");
 };
 
@@ -497,48 +495,246 @@ __global__ __launch_bounds__(256) void trdx_cert_kernel(const int* __restrict__ 
     if (!ok) atomicAdd(nrej, 1);
     if (ok && work) atomicAdd(work, 1ull);
   }
-  if (!ok) return;
-  double* Zb = wsm + LY::W_ZB;
-  for (int e = t; e < TNX * sh.nvec; e += 256) {
-    const int i = e / sh.nvec, c = e - i * sh.nvec;
-    Zb[(long)i * TMX + c] = Zg[(long)i * TMX + c] * zs[c];
-  }
 }
 
-// ================= triangular factors of the blocks of 64 reflectors (LAPACK dlarft, forward / columnwise) =================
-//   H_k0 ... H_k0+63 = I - V T V^T,  T upper triangular:  T_ii = tau_i,  T(0:i, i) = -tau_i T(0:i, 0:i) (V^T v_i)
-// from the block Gram  Gb = V_b V_b^T  (batched GEMM).  One workgroup (64 threads: thread = row of T) per block and matrix.
-template <typename LY>
-__global__ __launch_bounds__(64) void trdx_larft_kernel(const int* __restrict__ act, double* __restrict__ ws) {
-  constexpr int TNX = LY::TNX;
-  // G is symmetric: thread l reads G[b2][c] as Gs[c][b2] (lanes walk b2 = l + k: consecutive addresses); row l of T is kept as
-  // column l of Tt (address b2 * 64 + l: stride 65 over the lanes) -- both conflict free without padding, 2 x 32 KB
-  extern __shared__ __attribute__((aligned(16))) double lsm[];  // 2 x 64 x 64 doubles (64 KB: set as a dynamic size)
-  double (*Gs)[XRB] = reinterpret_cast<double (*)[XRB]>(lsm);
-  double (*Tt)[XRB] = reinterpret_cast<double (*)[XRB]>(lsm + XRB * XRB);
-  const int kb = blockIdx.x, bm = blockIdx.y, l = threadIdx.x;
+// ================= back-transformation on the matrix cores =================
+// A chunk of the Householder vectors -- reflectors 64 kb .. 64 kb + 63 (rows of Hs), matrix rows 64 c .. 64 c + 63 -- goes through
+// LDS as Vs[reflector][row]; thread t carries rows 2 (t & 31), + 1 of reflectors (t >> 5) + 8 q: a load instruction reads 512
+// contiguous bytes per reflector, the LDS stores are conflict free.
+__device__ __forceinline__ void vchunk_load(const double* __restrict__ Hs, const int nx, const int kb, const int c, const int t,
+                                            double (&r)[16]) {
+  const double* p = Hs + (long)(64 * kb + (t >> 5)) * nx + 64 * c + 2 * (t & 31);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double2 v = *reinterpret_cast<const double2*>(p + (long)8 * q * nx);
+    r[2 * q] = v.x;
+    r[2 * q + 1] = v.y;
+  }
+}
+__device__ __forceinline__ void vchunk_store(double* __restrict__ Vs, const int pitch, const int t, const double (&r)[16]) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    *reinterpret_cast<double2*>(Vs + ((t >> 5) + 8 * q) * pitch + 2 * (t & 31)) = make_double2(r[2 * q], r[2 * q + 1]);
+}
+
+// Triangular factors of the compact-WY blocks (LAPACK dlarft, forward / columnwise): one workgroup (256 threads) per block of 64
+// reflectors and matrix.
+//   H_k0 ... H_k0+63 = I - V^T T V  (V = the block's rows of Hs),  T upper triangular:  T_ii = tau_i,
+//   T(0:i, i) = -tau_i T(0:i, 0:i) (V v_i)
+// The block Gram  G = V V^T  (lower triangle, 10 tiles of 16 x 16) accumulates on the matrix cores: chunk by chunk through LDS,
+// wave w takes the chunk's rows 16 w .. 16 w + 15 (the four partial Grams are added in wave order); then one wave builds T column
+// by column.  (Rounds 3-4 ran 8 batched GEMMs with a quarter-filled 128 x 128 tile each, and a 64-thread dlarft kernel.)
+constexpr int TF_VP = 66, TF_GP = 66, TF_TP = 65;
+constexpr int TF_LDS_DOUBLES = 64 * TF_VP + 64 * TF_GP;
+
+template <int NX>
+__global__ __launch_bounds__(256) void trdx_tfac_kernel(const int* __restrict__ act, double* __restrict__ ws) {
+  using LY = LX<NX>;
+  extern __shared__ __attribute__((aligned(16))) double smt[];
+  double* Vs = smt;                // [64][TF_VP]; later T^T [64][TF_TP]
+  double* Gs = smt + 64 * TF_VP;   // [64][TF_GP]
+  const int kb = blockIdx.x, bm = blockIdx.y, t = threadIdx.x, w = t >> 6, l = t & 63, kq = l >> 4, li = l & 15;
   if (act[bm] != bm) return;
   double* wsm = ws + (long)bm * LY::W_PER;
-  const double* Gb = wsm + LY::W_GB + (long)kb * XRB * XRB;
-  for (int c = 0; c < XRB; ++c) {
-    Gs[c][l] = Gb[c * XRB + l];
-    Tt[c][l] = 0.0;
-  }
-  __syncthreads();
-  for (int c = 0; c < XRB; ++c) {  // column c only needs the columns before it; row l of T is this thread's
-    const double tau = wsm[LY::W_TG + 2 * TNX + XRB * kb + c];
-    double v = 0.0;
-    if (l == c) v = tau;
-    else if (l < c) {
-      double accv = 0.0;
-      for (int b2 = l; b2 < c; ++b2) accv = fma(Tt[b2][l], Gs[c][b2], accv);
-      v = -tau * accv;
+  const double* Hs = wsm + LY::W_HS;
+  v4f64 g[10];  // tile (i, j), j <= i, at i (i + 1) / 2 + j
+#pragma unroll
+  for (int e = 0; e < 10; ++e) g[e] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  double stg[16];
+  vchunk_load(Hs, NX, kb, kb, t, stg);
+  for (int c = kb; c < LY::NBLK; ++c) {
+    __syncthreads();
+    vchunk_store(Vs, TF_VP, t, stg);
+    __syncthreads();
+    if (c + 1 < LY::NBLK) vchunk_load(Hs, NX, kb, c + 1, t, stg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double f[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f[q] = Vs[(16 * q + li) * TF_VP + 16 * w + kq + 4 * s];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+          g[i * (i + 1) / 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i], f[j], g[i * (i + 1) / 2 + j], 0, 0, 0);
     }
-    Tt[c][l] = v;  // T[l][c]
+  }
+  for (int ww = 0; ww < 4; ++ww) {  // G = the waves' parts, added in wave order
+    if (w == ww) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double* pg = Gs + (16 * i + kq + 4 * r) * TF_GP + 16 * j + li;
+            const double v = g[i * (i + 1) / 2 + j][r];
+            *pg = (ww == 0) ? v : *pg + v;
+          }
+    }
+    __syncthreads();
+  }
+  // T column by column (column c only needs the columns before it); thread l < 64 owns row l, kept as column l of Tt
+  double* Tt = Vs;
+  if (w == 0) {
+    for (int c = 0; c < XRB; ++c) {
+      const double tau = wsm[LY::W_TG + 2 * NX + XRB * kb + c];
+      double v = 0.0;
+      if (l == c) v = tau;
+      else if (l < c) {
+        double accv = 0.0;
+        for (int b2 = l; b2 < c; ++b2) accv = fma(Tt[b2 * TF_TP + l], Gs[c * TF_GP + b2], accv);
+        v = -tau * accv;
+      }
+      Tt[c * TF_TP + l] = v;  // T[l][c]   (one wave: its LDS operations complete in order)
+    }
   }
   __syncthreads();
   double* Tf = wsm + LY::W_TF + (long)kb * XRB * XRB;
-  for (int r = 0; r < XRB; ++r) Tf[r * XRB + l] = Tt[l][r];  // row-major T[r][l]
+  for (int e = t; e < XRB * XRB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Tf[e] = Tt[c * TF_TP + r];  // row-major T[r][c]
+  }
+}
+
+// Z <- H_0 H_1 ... Z: the blocks in reverse order, each  Z -= V^T (T (V Z))  on rows 64 kb ..  One workgroup per 32 (16 above order
+// 512) columns of Z and matrix: the columns are independent, so a workgroup carries its slab of Z through ALL blocks in the
+// accumulator registers of the matrix cores (row tile rt = 4 t + w of wave w: NX / 64 tiles of 16 rows per wave) -- the D layout
+// of v_mfma_f64_16x16x4 is also its B layout, so  S = V Z  takes the tiles straight from the registers; V passes through LDS
+// twice per block (S, then the update), T_b S once.  (Rounds 3-4: three batched GEMMs per block with mostly empty 128 x 128 tiles,
+// 24 launches per solve that took as long as the tridiagonalisation.)
+template <int NX>
+struct XZ {
+  static constexpr int CT = NX > 512 ? 1 : 2;  // column tiles of 16 per workgroup
+  static constexpr int NC = 16 * CT;
+  static constexpr int TPW = NX / 64;          // row tiles per wave
+  // LDS pitches: a 32-lane half of a ds_read_b64 (k-lanes kq in {0, 1} or {2, 3}, 16 lanes li each) is conflict free when its
+  // 32 addresses differ mod 32 doubles.  Vs[reflector][row], pitch 66: S = V Z reads reflector 16 mi + li, row .. + kq
+  // (2 li + kq); the products whose k index is a reflector take k-step s, lane kq as reflector kmap(s, kq) = 8 kq + ..., so that
+  // the update's Vs[kmap][.. + li] (16 kq + li) and S / C [kmap][16 ct + li] with pitch NC + 2 (16 kq + li) are conflict free too.
+  static constexpr int VP = 66;
+  static constexpr int SP = NC + 2;
+  static constexpr int LDS_DOUBLES = 64 * VP + 2 * 64 * SP;
+  __device__ static __forceinline__ int kmap(const int s, const int kq) { return 8 * kq + (s & 7) + 32 * (s >> 3); }
+};
+
+template <int NX>
+__global__ __launch_bounds__(256) void trdx_back_kernel(const int* __restrict__ act, double* __restrict__ ws, const TrdShape sh) {
+  using LY = LX<NX>;
+  using K = XZ<NX>;
+  constexpr int CT = K::CT, NC = K::NC, TPW = K::TPW, VP = K::VP, SP = K::SP, TMX = LY::TMX;
+  extern __shared__ __attribute__((aligned(16))) double smz[];
+  double* Vs = smz;
+  double* Ss = smz + 64 * VP;
+  double* Cs = Ss + 64 * SP;
+  const int bm = blockIdx.y, t = threadIdx.x, w = t >> 6, l = t & 63, kq = l >> 4, li = l & 15;
+  if (act[bm] != bm) return;
+  double* wsm = ws + (long)bm * LY::W_PER;
+  const double* Hs = wsm + LY::W_HS;
+  const int c0 = NC * blockIdx.x;
+  v4f64 z[TPW][CT];  // z[tt][ct][r] = Z[64 tt + 16 w + kq + 4 r][c0 + 16 ct + li], normalised on the way in
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = c0 + 16 * ct + li;
+    const double zs = wsm[LY::W_LG + TMX + col];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[tt][ct][r] = wsm[LY::W_ZG + (long)(64 * tt + 16 * w + kq + 4 * r) * TMX + col] * zs;
+  }
+  for (int kb = LY::NBLK - 1; kb >= 0; --kb) {
+    double tf[16];  // rows 16 w .. of T_b (A operand of C = T S)
+    {
+      const double* Tf = wsm + LY::W_TF + (long)kb * XRB * XRB + (16 * w + li) * XRB;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) tf[s] = Tf[K::kmap(s, kq)];
+    }
+    v4f64 sp[4][CT];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) sp[mi][ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    // ---- S = V Z over rows 64 kb .. (chunk tt holds this wave's row tile tt) ----
+    double stg[16];
+  vchunk_load(Hs, NX, kb, kb, t, stg);
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      if (tt >= kb) {
+        __syncthreads();  // (the readers of the previous chunk are done)
+        vchunk_store(Vs, VP, t, stg);
+        __syncthreads();
+        if (tt + 1 < TPW) vchunk_load(Hs, NX, kb, tt + 1, t, stg);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          double a[4];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) a[mi] = Vs[(16 * mi + li) * VP + 16 * w + kq + 4 * s];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              sp[mi][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], z[tt][ct][s], sp[mi][ct], 0, 0, 0);
+        }
+      }
+    }
+    for (int ww = 0; ww < 4; ++ww) {  // the waves' parts, added in wave order
+      if (w == ww) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              double* ps = Ss + (16 * mi + kq + 4 * r) * SP + 16 * ct + li;
+              *ps = (ww == 0) ? sp[mi][ct][r] : *ps + sp[mi][ct][r];
+            }
+      }
+      __syncthreads();
+    }
+    // ---- C = T_b S: wave w its 16 rows ----
+    {
+      v4f64 cc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) cc[ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          cc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[s], Ss[K::kmap(s, kq) * SP + 16 * ct + li], cc[ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(16 * w + kq + 4 * r) * SP + 16 * ct + li] = cc[ct][r];
+    }
+    // ---- Z -= V^T C ----
+    vchunk_load(Hs, NX, kb, kb, t, stg);
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      if (tt >= kb) {
+        __syncthreads();  // (C is complete; the readers of the previous chunk are done)
+        vchunk_store(Vs, VP, t, stg);
+        __syncthreads();
+        if (tt + 1 < TPW) vchunk_load(Hs, NX, kb, tt + 1, t, stg);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int kr = K::kmap(s, kq);
+          const double a = -Vs[kr * VP + 16 * w + li];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            z[tt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Cs[kr * SP + 16 * ct + li], z[tt][ct], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // (S and C may be rewritten)
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = c0 + 16 * ct + li;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wsm[LY::W_ZB + (long)(64 * tt + 16 * w + kq + 4 * r) * TMX + col] = z[tt][ct][r];
+  }
 }
 
 // ================= result: column c of the matrix <- lam_c v_c (c < nvec), zeros elsewhere; 64 x 64 tiles through LDS ========
@@ -593,18 +789,20 @@ static int trdx_prepare_t() {
       rc = hipFuncSetAttribute((const void*)trd_c_kernel<LY, XA<NX>::VPW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * trd_c_lds_doubles<LY, XA<NX>::VPW>()));
     if (rc == hipSuccess)
-      rc = hipFuncSetAttribute((const void*)trdx_larft_kernel<LY>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(double) * 2 * XRB * XRB));
+      rc = hipFuncSetAttribute((const void*)trdx_tfac_kernel<NX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * TF_LDS_DOUBLES));
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute((const void*)trdx_back_kernel<NX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * XZ<NX>::LDS_DOUBLES));
   });
   MUSED_CHECK_HIP(rc);
-  return gemm_f64_prepare_all();
+  return MUSED_OK;
 }
 
 template <int NX>
 static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* rep, int* done, int* act, int* jrep, int* nrej,
                         double* ws, hipStream_t st, unsigned long long* work, hipEvent_t after_a, long long* prof, double* lam_out) {
   using LY = LX<NX>;
-  const long per = LY::W_PER;
   constexpr int VPW = XA<NX>::VPW;
   const int nvec = sh.nvec, nch32 = nvec / 32, nchc = nvec / VPW;
   hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(XA<NX>::NT), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws, prof);
@@ -614,30 +812,10 @@ static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* re
   hipLaunchKernelGGL((trd_c_kernel<LY, VPW>), dim3(nchc * batch), dim3(128), c_lds, st, rep, ws, sh);
   hipLaunchKernelGGL(trdx_cert_kernel<LY>, dim3(batch), dim3(256), 0, st, rep, ws, done, act, jrep, nrej, work, sh);
   MUSED_LAUNCH_CHECK();
-  int rc;
-  // block Grams and triangular factors of the compact-WY blocks
-  for (int b = 0; b < LY::NBLK; ++b) {
-    const double* Vb = ws + LY::W_HS + (long)XRB * b * NX + XRB * b;  // rows 64 b .., columns 64 b .. (zeros to the left)
-    if ((rc = gemm_f64(true, true, Vb, NX, per, Vb, NX, per, ws + LY::W_GB + (long)b * XRB * XRB, XRB, per, XRB, XRB,
-                       NX - XRB * b, batch, 1.0, st, act)))
-      return rc;
-  }
-  hipLaunchKernelGGL(trdx_larft_kernel<LY>, dim3(LY::NBLK, batch), dim3(64), sizeof(double) * 2 * XRB * XRB, st, act, ws);
-  MUSED_LAUNCH_CHECK();
-  // Z <- H_0 H_1 ... Z: blocks in reverse order, each  Z -= V_b^T (T_b (V_b Z))  on rows 64 b ..
-  for (int b = LY::NBLK - 1; b >= 0; --b) {
-    const double* Vb = ws + LY::W_HS + (long)XRB * b * NX + XRB * b;
-    double* Zb = ws + LY::W_ZB + (long)XRB * b * LY::TMX;
-    const int K = NX - XRB * b;
-    if ((rc = gemm_f64(true, false, Vb, NX, per, Zb, LY::TMX, per, ws + LY::W_S, LY::TMX, per, XRB, nvec, K, batch, 1.0, st, act)))
-      return rc;
-    if ((rc = gemm_f64(true, false, ws + LY::W_TF + (long)b * XRB * XRB, XRB, per, ws + LY::W_S, LY::TMX, per, ws + LY::W_C,
-                       LY::TMX, per, XRB, nvec, XRB, batch, 1.0, st, act)))
-      return rc;
-    if ((rc = gemm_f64_acc(false, false, Vb, NX, per, ws + LY::W_C, LY::TMX, per, Zb, LY::TMX, per, K, nvec, XRB, batch, -1.0, st,
-                           act)))
-      return rc;
-  }
+  // triangular factors of the compact-WY blocks, then Z <- H_0 H_1 ... Z (one workgroup per 32 / 16 columns of Z)
+  hipLaunchKernelGGL(trdx_tfac_kernel<NX>, dim3(LY::NBLK, batch), dim3(256), sizeof(double) * TF_LDS_DOUBLES, st, act, ws);
+  hipLaunchKernelGGL(trdx_back_kernel<NX>, dim3(nvec / XZ<NX>::NC, batch), dim3(256), sizeof(double) * XZ<NX>::LDS_DOUBLES, st, act,
+                     ws, sh);
   hipLaunchKernelGGL(trdx_store_kernel<LY>, dim3((NX / 64) * (NX / 64), batch), dim3(256), 0, st, act, ws, Gc, sh, lam_out);
   MUSED_LAUNCH_CHECK();
   return MUSED_OK;
