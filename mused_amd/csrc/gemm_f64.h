@@ -366,20 +366,6 @@ struct EpiStore {
   }
 };
 
-// C += alpha * acc (the blocked back-transformation of the direct eigensolver, trdx.hip: Z -= V (T V^T Z))
-struct EpiAccum {
-  double* C;
-  long ldc;
-  long strideC;
-  double alpha;
-  __device__ __forceinline__ void operator()(int z, int row, int col, double v) const {
-    double* p = C + (long)z * strideC + (long)row * ldc + col;
-    *p = fma(alpha, v, *p);
-  }
-  __device__ __forceinline__ double value(int, int, double v) const { return alpha * v; }   // (never launched symmetric)
-  __device__ __forceinline__ void put(int, int, int, double) const {}
-};
-
 template <typename TA, typename TB, bool A_KC, bool B_KC, bool VEC, typename Epi>
 int gemm_f64_prepare_t() {
   // > 64 KiB of dynamic LDS needs the attribute once per kernel; done outside stream capture.  Several host

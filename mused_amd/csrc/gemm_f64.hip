@@ -23,9 +23,6 @@ int gemm_f64_prepare_all() {
   PREP(true, true, true); PREP(true, true, false); PREP(true, false, true); PREP(true, false, false);
   PREP(false, true, true); PREP(false, true, false); PREP(false, false, true); PREP(false, false, false);
 #undef PREP
-  // the accumulating variant in the two layouts the back-transformation uses (trdx.hip)
-  rc |= gemm_f64_prepare_t<double, double, false, false, true, EpiAccum>();
-  rc |= gemm_f64_prepare_t<double, double, false, false, false, EpiAccum>();
   return rc ? MUSED_ERR_HIP : MUSED_OK;
 }
 
@@ -40,24 +37,6 @@ int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, cons
   // Gram products (A A^T: same operand, same layout, square result): tiles on or above the diagonal + mirrored stores
   g.sym = (A == B && a_kc == b_kc && lda == ldb && strideA == strideB && M == N) ? 1 : 0;
   EpiStore epi{C, ldc, strideC, alpha};
-  const bool vec = vec_ok<double>(A, lda, strideA) && vec_ok<double>(B, ldb, strideB);
-  if (a_kc && b_kc) return gemm_f64_launch_t<double, double, true, true>(g, batch, epi, vec, stream);
-  if (a_kc && !b_kc) return gemm_f64_launch_t<double, double, true, false>(g, batch, epi, vec, stream);
-  if (!a_kc && b_kc) return gemm_f64_launch_t<double, double, false, true>(g, batch, epi, vec, stream);
-  return gemm_f64_launch_t<double, double, false, false>(g, batch, epi, vec, stream);
-}
-
-// C[z] += alpha * opA(A[z]) * opB(B[z])
-int gemm_f64_acc(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb, long strideB,
-                 double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha, hipStream_t stream,
-                 const int* rep) {
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.strideA = strideA; g.strideB = strideB;
-  g.M = M; g.N = N; g.K = K; g.splitk = 0; g.kchunk = 0;
-  g.rep = rep;
-  g.sym = 0;
-  EpiAccum epi{C, ldc, strideC, alpha};
   const bool vec = vec_ok<double>(A, lda, strideA) && vec_ok<double>(B, ldb, strideB);
   if (a_kc && b_kc) return gemm_f64_launch_t<double, double, true, true>(g, batch, epi, vec, stream);
   if (a_kc && !b_kc) return gemm_f64_launch_t<double, double, true, false>(g, batch, epi, vec, stream);

@@ -28,9 +28,6 @@ int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, cons
              long strideB, double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha,
              hipStream_t stream, const int* rep = nullptr);
 // rep (device, batch ints, optional): entry z is computed only when rep[z] == z (duplicates are skipped)
-int gemm_f64_acc(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb, long strideB,
-                 double* C, long ldc, long strideC, int M, int N, int K, int batch, double alpha, hipStream_t stream,
-                 const int* rep = nullptr);  // C[z] += alpha * opA(A[z]) * opB(B[z])
 
 // Sets the dynamic-LDS attribute of every plain GEMM instantiation (call before stream capture).
 int gemm_f64_prepare_all();
@@ -96,6 +93,11 @@ int eig_plan_run_inplace(EigPlan* p, double* evals, double* V, hipStream_t strea
 size_t trd_workspace_doubles(int batch);
 int trd_prepare();
 bool trd_supports(int n, int ldn, int need);
+// the order-256 tridiagonalisation alone (the blocked solver's tail): see trd.hip
+long trd_tail_ws_per();
+long trd_tail_off_hs();
+long trd_tail_off_tg();
+int trd_tail_launch(const double* G, const int* rep, double* ws, int batch, hipStream_t st);
 int trd_solve(double* Gc, int n, int ldn, int need, bool cert_all, int batch, const int* rep, int* done, double* ws,
               hipStream_t st, long long* dbg_clk = nullptr, unsigned long long* work = nullptr, hipEvent_t after_a = nullptr,
               double* lam_out = nullptr);  // lam_out (batch x ldn, optional): eigenvalues of the solved matrices (zeros behind them)

@@ -570,6 +570,22 @@ int trd_prepare() {
   return MUSED_OK;
 }
 
+// The tridiagonalisation alone on `batch` symmetric matrices of order 256 (G: batch x 256 x 256 column-major; only the lower block
+// triangle of 32 x 32 blocks is read, the diagonal blocks whole).  The blocked solver (trdx.hip) hands the trailing 256 x 256 of its
+// larger orders over to it.  ws: batch x trd_tail_ws_per() doubles: Householder vectors at trd_tail_off_hs() (row k = v_k, 256 x
+// 256; row 255 is not written), d / e / tau (256 each) at trd_tail_off_tg().
+long trd_tail_ws_per() { return W_PER; }
+long trd_tail_off_hs() { return W_HS; }
+long trd_tail_off_tg() { return W_TG; }
+int trd_tail_launch(const double* G, const int* rep, double* ws, int batch, hipStream_t st) {
+  TrdDebug dbg{nullptr, nullptr};
+  TrdShape sh;
+  sh.n = TN; sh.ldn = TN; sh.off = 0; sh.nvec = TM; sh.need = TM; sh.cert_all = 0;
+  hipLaunchKernelGGL(trd_a_kernel<false>, dim3(batch), dim3(TNT), sizeof(double) * L_A_TOTAL, st, G, rep, ws, dbg, sh);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
 bool trd_supports(int n, int ldn, int need) { return n >= 2 && n <= TN && ldn >= n && ldn <= TN && need >= 1 && need <= TM && need <= n; }
 
 // Solves the matrices of Gc (batch x ldn x ldn column-major, symmetric of order n <= ldn <= 256, zero padded) in place:

@@ -27,6 +27,7 @@
 namespace mused {
 
 constexpr int XRB = 64;  // reflectors per compact-WY block of the back-transformation
+constexpr int XTAIL = 256;  // order of the trailing matrix handed to the register-resident tridiagonalisation (trd.hip)
 
 template <int NX>
 struct LX {
@@ -109,7 +110,8 @@ struct XA {
   static constexpr int VPW = NX > 512 ? 8 : 16;  // vectors per workgroup of kernel C (their pivot sequences fill its LDS)
   static constexpr int U_DOUBLES = (NW * NX > 2 * NX * PITCH) ? NW * NX : 2 * NX * PITCH;
   static constexpr int LDS_DOUBLES = NX + NW * 34 + 40 + 34 + U_DOUBLES;
-  static_assert(NT % 64 == 0 && NT <= 512 && LDS_DOUBLES * 8 <= 160 * 1024, "trdx: unsupported order");
+  static constexpr int JEND = NX - XTAIL;       // columns reduced here; the trailing XTAIL x XTAIL goes to trd.hip
+  static_assert(NT % 64 == 0 && NT <= 512 && LDS_DOUBLES * 8 <= 160 * 1024 && JEND >= NB && JEND % NB == 0, "trdx: unsupported order");
 };
 
 template <int NX>
@@ -119,10 +121,11 @@ constexpr int trdx_a_lds_doubles() {
 
 template <int NX>
 __global__ __launch_bounds__(XA<NX>::NT) void trdx_a_kernel(const double* __restrict__ Gc, const int* __restrict__ rep,
-                                                            double* __restrict__ ws, long long* __restrict__ prof) {
+                                                            double* __restrict__ ws, long long* __restrict__ prof,
+                                                            double* __restrict__ g22) {
   using LY = LX<NX>;
   using K = XA<NX>;
-  constexpr int RPT = K::RPT, NT = K::NT, NB = K::NB, NW = K::NW, PITCH = K::PITCH;
+  constexpr int RPT = K::RPT, NT = K::NT, NB = K::NB, NW = K::NW, PITCH = K::PITCH, JEND = K::JEND;
   constexpr int NS = NX / 16, NT128 = (NX + 127) / 128;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int bm = blockIdx.x;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(XA<NX>::NT) void trdx_a_kernel(const double* __rest
       plast = now;
     }
   };
-  for (int j0 = 0; j0 < NX; j0 += NB) {
+  for (int j0 = 0; j0 < JEND; j0 += NB) {
     double anext[RPT];  // column j0 of the matrix as the last panel update left it
 #pragma unroll
     for (int h = 0; h < RPT; ++h) anext[h] = A[(long)j0 * NX + t + h * NT];
@@ -430,8 +433,38 @@ __global__ __launch_bounds__(XA<NX>::NT) void trdx_a_kernel(const double* __rest
     __syncthreads();  // the updated matrix is visible to the whole workgroup; U may be reused
     ptick(3);
   }
+  {  // the trailing XTAIL x XTAIL as the last panel update left it, for the register-resident reduction of trd.hip (which reads
+     // whole diagonal blocks: the lower triangle is mirrored -- the upper one is not maintained here)
+    double* T22 = g22 + (long)bm * XTAIL * XTAIL;
+    for (int e = t; e < XTAIL * XTAIL; e += NT) {
+      const int jj = e / XTAIL, ii = e % XTAIL;
+      T22[e] = (ii >= jj) ? A[(long)(JEND + jj) * NX + JEND + ii] : A[(long)(JEND + ii) * NX + JEND + jj];
+    }
+  }
   if (prof && t == 0)
     for (int q = 0; q < 4; ++q) prof[(long)bm * 4 + q] = pacc[q];
+}
+
+// d / e / tau and the Householder vectors of the trailing XTAIL columns (trd.hip's workspace layout) -> this solver's layout: row
+// JEND + k of Hs = [zeros | v_k].  Grid (XTAIL, batch).
+template <int NX>
+__global__ __launch_bounds__(256) void trdx_tail_merge_kernel(const int* __restrict__ rep, double* __restrict__ ws,
+                                                              const double* __restrict__ wst, const long tper, const long ohs,
+                                                              const long otg) {
+  using LY = LX<NX>;
+  constexpr int JEND = XA<NX>::JEND;
+  const int k = blockIdx.x, bm = blockIdx.y;
+  if (rep && rep[bm] != bm) return;
+  double* wsm = ws + (long)bm * LY::W_PER;
+  const double* tw = wst + (long)bm * tper;
+  for (int row = threadIdx.x; row < NX; row += 256)  // (the last reflector is the identity: its row is not written by trd.hip)
+    wsm[LY::W_HS + (long)(JEND + k) * NX + row] = (row >= JEND && k < XTAIL - 1) ? tw[ohs + (long)k * XTAIL + row - JEND] : 0.0;
+  if (k == 0) {
+    const int i = threadIdx.x;  // (XTAIL == 256 threads)
+    wsm[LY::W_TG + JEND + i] = tw[otg + i];
+    wsm[LY::W_TG + NX + JEND + i] = tw[otg + XTAIL + i];
+    wsm[LY::W_TG + 2 * NX + JEND + i] = tw[otg + 2 * XTAIL + i];
+  }
 }
 
 // ================= certificate + normalisation: one workgroup per matrix =================
@@ -796,7 +829,7 @@ static int trdx_prepare_t() {
                                (int)(sizeof(double) * XZ<NX>::LDS_DOUBLES));
   });
   MUSED_CHECK_HIP(rc);
-  return MUSED_OK;
+  return trd_prepare();
 }
 
 template <int NX>
@@ -805,8 +838,17 @@ static int trdx_solve_t(double* Gc, const TrdShape& sh, int batch, const int* re
   using LY = LX<NX>;
   constexpr int VPW = XA<NX>::VPW;
   const int nvec = sh.nvec, nch32 = nvec / 32, nchc = nvec / VPW;
-  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(XA<NX>::NT), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws, prof);
+  double* g22 = ws + (size_t)batch * LY::W_PER;             // batch x XTAIL x XTAIL
+  double* wst = g22 + (size_t)batch * XTAIL * XTAIL;        // batch x trd_tail_ws_per()
+  hipLaunchKernelGGL(trdx_a_kernel<NX>, dim3(batch), dim3(XA<NX>::NT), sizeof(double) * trdx_a_lds_doubles<NX>(), st, Gc, rep, ws, prof,
+                     g22);
   if (after_a) MUSED_CHECK_HIP(hipEventRecord(after_a, st));
+  {
+    const int rc_t = trd_tail_launch(g22, rep, wst, batch, st);
+    if (rc_t) return rc_t;
+  }
+  hipLaunchKernelGGL(trdx_tail_merge_kernel<NX>, dim3(XTAIL, batch), dim3(256), 0, st, rep, ws, wst, trd_tail_ws_per(), trd_tail_off_hs(),
+                     trd_tail_off_tg());
   hipLaunchKernelGGL((trd_b_kernel<128, LY>), dim3(nch32 * batch), dim3(128), 0, st, rep, ws, sh);
   constexpr size_t c_lds = sizeof(double) * trd_c_lds_doubles<LY, VPW>();
   hipLaunchKernelGGL((trd_c_kernel<LY, VPW>), dim3(nchc * batch), dim3(128), c_lds, st, rep, ws, sh);
@@ -840,7 +882,7 @@ bool trdx_supports(int ldn, int need) {
   }
 
 size_t trdx_workspace_doubles(int ldn, int batch) {
-#define TRDX_WS(NX) return (size_t)batch * LX<NX>::W_PER
+#define TRDX_WS(NX) return (size_t)batch * ((size_t)LX<NX>::W_PER + (size_t)XTAIL * XTAIL + (size_t)trd_tail_ws_per())
   TRDX_DISPATCH(ldn, TRDX_WS)
   return 0;
 }
