@@ -778,10 +778,13 @@ def main():
                             "matrix: 256 KB read (lower triangle of G) + 512 KB of Householder vectors written.",
                 }
                 if n > 256:
-                    # orders 320 .. 512 run the BLOCKED solver (csrc/trdx.hip): its tridiagonalisation streams the lower triangle of
-                    # the matrix once per column -- bytes, not flops, are what it is priced on
-                    ldn = -(-n // 64) * 64
-                    bytes_a = ldn ** 3 // 6 * 8 + 2 * ldn * ldn * 8   # symv stream + the matrix read once + Householder vectors written
+                    # orders 320 .. 1024 run the BLOCKED solver (csrc/trdx.hip): its tridiagonalisation streams the lower triangle of
+                    # the matrix once per column -- bytes, not flops, are what it is priced on.  It reduces the first ldn - 256
+                    # columns; the trailing 256 x 256 goes to the register-resident trd_a_kernel.
+                    ldn = -(-n // 64) * 64 if n <= 512 else -(-n // 128) * 128
+                    jend = ldn - 256
+                    # symv stream of columns 0 .. jend - 1 + the matrix read once + Householder vectors of those columns + the tail block
+                    bytes_a = (ldn ** 3 - 256 ** 3) // 6 * 8 + ldn * ldn * 8 + jend * ldn * 8 + 256 * 256 * 8
                     gbs_a = per_launch * bytes_a / (a_us * 1e-6) / 1e9
                     trx = None
                     try:
@@ -793,8 +796,9 @@ def main():
                         trx = None
                     roof = {
                         "kernel": f"trdx_a_kernel (blocked Householder tridiagonalisation of the direct eigensolver of the FD rotation, "
-                                  f"order {ldn}: one workgroup per Gram matrix, dlatrd panels of 16 columns, the symv streams the lower "
-                                  f"triangle of the panel-start matrix from L2 / Infinity Cache / HBM once per column), {per_launch:.1f} "
+                                  f"order {ldn}: one workgroup per Gram matrix, dlatrd panels of 16 columns over the first {jend} columns -- the "
+                                  f"symv streams the lower triangle of the panel-start matrix from L2 / Infinity Cache / HBM once per "
+                                  f"column -- the trailing 256 x 256 handed to the register-resident trd_a_kernel), {per_launch:.1f} "
                                   f"matrices solved per launch, {ns} independent launch streams",
                         "bound": "hbm", "achieved": gbs_a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_a / HBM_PEAK_GBS,
                         "traffic": trx, "launch_us": a_us, "launches_timed": n_launch,
@@ -802,11 +806,12 @@ def main():
                         "per_cu": {"achieved_gbs": bytes_a / (a_us * 1e-6) / 1e9,
                                    "note": "one workgroup = one CU per matrix: what a single CU pulls (64 B/clk of L1 = 150 GB/s is its ceiling)"},
                         "concurrent_launch_streams": ns,
-                        "solve": {"kernels": "trdx_a -> trd_b -> trd_c -> trdx_cert -> block Grams + trdx_larft -> 3 GEMMs per block of 64 "
-                                             "reflectors -> trdx_store (one HIP-event bracket)", "launch_us": launch_us,
+                        "solve": {"kernels": "trdx_a -> trd_a (trailing 256 x 256) -> trdx_tail_merge -> trd_b -> trd_c -> trdx_cert -> "
+                                             "trdx_tfac -> trdx_back -> trdx_store (one HIP-event bracket)", "launch_us": launch_us,
                                   "flop_per_matrix": flop_solve, "achieved_tflops": tfl},
-                        "note": "algorithmic bytes = n^3 / 6 doubles of symv reads (every column multiplies the trailing lower triangle) + "
-                                "n^2 doubles read (working copy) + n^2 written (Householder vectors); `launch_us` is the HIP-event time from "
+                        "note": "algorithmic bytes = (n^3 - 256^3) / 6 doubles of symv reads (each of the first n - 256 columns multiplies the "
+                                "trailing lower triangle) + n^2 doubles read (working copy) + the Householder vectors and the tail block "
+                                "written; `launch_us` is the HIP-event time from "
                                 "the start of the solver chain to the end of trdx_a_kernel on its launch stream with the other streams of "
                                 "the pipeline running beside it.  The kernel is latency-bound on the one tile (16 KB) a wave keeps in "
                                 "flight (DESIGN section 5b), far from the HBM roofline.",

@@ -41,14 +41,17 @@ algorithmic = {
 if XN:
     n = XN
     algorithmic = {
-        # symv stream of the lower triangle over the n columns + the matrix read once (working copy) + Householder vectors written
-        "trdx_a_kernel": n ** 3 // 6 * 8 + 2 * n * n * 8,
+        # symv stream of the lower triangle over the first n - 256 columns + the matrix read once (working copy) + the Householder
+        # vectors of those columns and the trailing 256 x 256 block written (the tail goes to trd_a_kernel)
+        "trdx_a_kernel": (n ** 3 - 256 ** 3) // 6 * 8 + n * n * 8 + (n - 256) * n * 8 + 256 * 256 * 8,
+        "trd_a_kernel": 256 * 257 // 2 * 8 + 254 * 256 * 8,
+        "trdx_tail_merge_kernel": 2 * 256 * n * 8,
         "trd_b_kernel": 3 * n * 8,
         "trd_c_kernel": None,
         "trdx_cert_kernel": None,
-        "trdx_larft_kernel": None,
+        "trdx_tfac_kernel": (n // 64) * (n // 64 + 1) // 2 * 64 * 64 * 8 + (n // 64) * 64 * 64 * 8,   # Householder blocks read, T factors written
+        "trdx_back_kernel": None,
         "trdx_store_kernel": None,
-        "gemm_f64_kernel": None,
     }
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --output-format csv -- python3 "
                  f"tools/{'pmc_trdx_run.py ' + str(XN) if XN else 'pmc_trd_run.py'} {batch}, MI355X (launches of {batch} matrices each)",
@@ -64,9 +67,9 @@ for k in sorted(set(fetch) | set(write)):
                             "write_bytes_per_matrix": wk * 1024.0 / batch, "traffic_bytes_per_matrix": t,
                             "algorithmic_bytes_per_matrix": algorithmic.get(k)}
 out["traffic_bytes_per_matrix"] = tot
-out["algorithmic_bytes_per_matrix_chain"] = (XN ** 3 // 6 * 8 + 2 * XN * XN * 8) if XN else 512 * 1024 + 256 * 1024
+out["algorithmic_bytes_per_matrix_chain"] = ((XN ** 3 - 256 ** 3) // 6 * 8 + 2 * XN * XN * 8) if XN else 512 * 1024 + 256 * 1024
 if XN:
-    out["note"] = ("trdx_a_kernel streams the lower triangle of the panel-start matrix once per column (n^3 / 6 doubles) from L2 / "
+    out["note"] = ("trdx_a_kernel streams the lower triangle of the panel-start matrix once per column of its first n - 256 columns from L2 / "
                    "Infinity Cache / HBM; the counters sit on the L2's memory side, so re-reads that hit the XCD's L2 are not in them")
 else:
   out["note"] = ("chain = trd_a -> trd_b -> trd_c -> trd_t -> trd_d; the Householder vectors (512 KB), the eigenvectors of T (256 KB) "

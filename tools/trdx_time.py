@@ -15,7 +15,7 @@ fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_dou
 fj = L.mused_debug_eig_time
 fj.restype = C.c_int
 fj.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
-cases = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(512, 256, 30), (512, 256, 120), (384, 128, 7), (384, 128, 20), (512, 128, 20)]
+cases = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(512, 256, 30), (512, 256, 120), (384, 128, 7), (384, 128, 20), (512, 128, 20), (768, 256, 8), (1024, 256, 8)]
 bufs = {}
 for n, need, batch in cases:
     if n not in bufs:
@@ -26,7 +26,7 @@ for n, need, batch in cases:
     done = (C.c_int * batch)()
     prof = torch.zeros(batch, 4, dtype=torch.int64, device="cuda")
     _lib.check(fn(ptr(G), n, need, batch, 3, C.byref(ms), C.byref(msa), done, ptr(prof) if os.environ.get("TRDX_PROF") else None, stream_ptr()))
-    line = f"order {n} top {need} batch {batch:4d}: direct {ms.value:8.3f} ms per solve (tridiagonalisation {msa.value:8.3f}), {sum(done)} of {batch} certified"
+    line = f"order {n} top {need} batch {batch:4d}: direct {ms.value:8.3f} ms per solve (blocked tridiagonalisation of the first {n - 256} columns {msa.value:8.3f}), {sum(done)} of {batch} certified"
     if "--jacobi" in os.environ.get("TRDX_TIME", "--jacobi"):
         ev = torch.zeros(batch, n, dtype=torch.float64, device="cuda")
         V = torch.zeros(batch, n, n, dtype=torch.float64, device="cuda")
@@ -36,5 +36,6 @@ for n, need, batch in cases:
         line += f" | one-sided Jacobi {mj.value:8.3f} ms"
     print(line, flush=True)
     if os.environ.get("TRDX_PROF"):
-        pr = prof.cpu().numpy().astype(np.float64).mean(axis=0) / 100.0   # s_memtime: 100 MHz -> us
-        print("      kernel A phases, us per matrix (thread 0): column + Householder %.0f | symv %.0f | reductions + w %.0f | panel update %.0f" % tuple(pr), flush=True)
+        pr = prof.cpu().numpy().astype(np.float64).mean(axis=0)
+        pr = 100.0 * pr / pr.sum()                                         # s_memtime ticks of thread 0 -> shares of the kernel
+        print("      blocked kernel A, shares of its time (thread 0): column + Householder %.0f %% | symv %.0f %% | reductions + w %.0f %% | panel update %.0f %%" % tuple(pr), flush=True)
