@@ -356,3 +356,42 @@ def test_blocked_direct_solver_rejects_clusters_and_leaves_the_matrix():
     np.testing.assert_allclose(lam[0, :128], np.sort(w)[::-1][:128], rtol=0, atol=1e-12 * 7.0)
     assert done[1] == 1 and np.abs(out[1]).max() < 1e-290            # zero matrix: nothing significant
     assert done[2] == 1                                               # identity: nothing survives the shrink
+
+
+@pytest.mark.parametrize("n", [320, 512, 640, 1024])
+def test_blocked_direct_solver_spectra_and_scales(n):
+    """The hybrid reduction (blocked columns, then the trailing 256 x 256 on the register-resident kernel) on spectra that stress
+    the hand-over: geometric decay over 12 decades, a spectrum that is exhausted inside the blocked columns (rank 40: the tail
+    block is rounding residue), one exhausted inside the tail (rank n - 100), and overall scales 1e-120 / 1e+120.  Every matrix is
+    either certified with accurate leading pairs or rejected and left untouched."""
+    rng = np.random.default_rng(7 * n)
+    need = min(256, n // 2)
+    nvec = 32 * ((need + 31) // 32)
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+
+    def with_spectrum(w):
+        G = (Q * w) @ Q.T
+        return 0.5 * (G + G.T)
+
+    geo = np.geomspace(1.0, 1e-12, n)
+    lowrank = np.r_[np.linspace(5.0, 1.0, 40), np.zeros(n - 40)]
+    tailrank = np.r_[np.linspace(9.0, 0.5, n - 100), np.zeros(100)]
+    lin = np.linspace(4.0, 0.01, n)
+    Gs = [with_spectrum(geo), with_spectrum(lowrank), with_spectrum(tailrank), with_spectrum(lin) * 1e-120,
+          with_spectrum(lin) * 1e120]
+    out, d, e, lam, res, done = run_trdx(Gs, n, need)
+    for b, G in enumerate(Gs):
+        if done[b] == 0:
+            assert np.array_equal(out[b], G)
+            continue
+        w = np.linalg.eigvalsh(G)[::-1]
+        scale = np.abs(w).max()
+        assert np.isfinite(lam[b, :nvec]).all()
+        np.testing.assert_allclose(lam[b, :nvec], w[:nvec], rtol=0, atol=5e-13 * scale)
+        cols = out[b].T
+        nrm = np.linalg.norm(cols[:, :nvec], axis=0)
+        sig = (w[:need] > 0) & ((w[:need] - w[need - 1]) > 1e-10 * w[0])
+        V = cols[:, :need][:, sig] / nrm[:need][sig]
+        assert np.abs(V.T @ V - np.eye(V.shape[1])).max() < 1e-9
+        assert np.abs(G @ V - V * w[:need][sig]).max() < 1e-10 * scale
+    assert done[0] == 1 and done[3] == 1 and done[4] == 1      # (the rank-deficient ones may be rejected: zero clusters at the cut)
