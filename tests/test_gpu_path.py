@@ -344,6 +344,26 @@ def test_swfd_matches_oracle_over_a_stream(kind):
     dev.close()
 
 
+def test_swfd_orders_padded_into_the_blocked_solver():
+    """l = 150: rotations of order 300 (zero padded to 320) and queries of order 450 / 600 (padded to 512 / 640) -- orders that
+    are not the blocked direct solver's own, solved embedded in the next one it has, its trailing 256 x 256 on the register-resident
+    kernel.  Device == specification over an epoch end (parity unpinned, as for every SWFD test)."""
+    from mused_amd import synth
+
+    N, ell, d = 900, 150, 320
+    X, _ = synth.make_stream("blob", N + 520, d, 4)
+    R = float((X.astype(np.float64) ** 2).sum(1).max())
+    dev, ora = _swfd_pair(N, R, d, ell)
+    t = 0
+    for step in [300, 450, 170, 500]:
+        blk = X[t : t + step]
+        dev.fit(blk)
+        ora.fit(blk)
+        t += step
+        _compare(dev, ora, f"l=150 t={t}")
+    dev.close()
+
+
 def test_swfd_device_rows_int64_and_per_row_fit():
     """mused wiring: d = window size, rows of the int64 fused adjacency, one fit() per row (main.py:65-67)."""
     W, ell = 96, 6
