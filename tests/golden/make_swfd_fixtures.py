@@ -78,6 +78,33 @@ def case_sketch_checks(tag, N, d, ell, steps, seed=0):
                         delta=np.array(dlt), gram_idx=idx, gram_block=np.array(blk))
 
 
+def case_headline_lanes(tag, W, d, ell, n_lanes, steps, seed=0):
+    """The configuration bench.py times (N = W = 10,000, d = 1024, l = 128): the specification's sketch over the first sum(steps)
+    rows of `n_lanes` different windows of the benchmark stream (one sketch each, R from window 0) -- singular values, level, final
+    shrink and a sampled 64 x 64 block of B^T B after every step."""
+    rows = sum(steps)
+    R = float((synth.stream_window("blob", 0, W, d, seed)[0].astype(np.float64) ** 2).sum(1).max())
+    idx = np.linspace(0, d - 1, 64).astype(np.int64)
+    sig, lvl, dlt, blk, dig = [], [], [], [], []
+    t0 = time.time()
+    for b in range(n_lanes):
+        X = synth.stream_window("blob", b, W, d, seed)[0][:rows]
+        dig.append(synth.array_digest(X))
+        ora = OraSWFD(N=W, R=R, d=d, sketch_dim=ell)
+        t = 0
+        s_b, l_b, d_b, g_b = [], [], [], []
+        for st in steps:
+            ora.fit(X[t:t + st].astype(np.float64))
+            t += st
+            B, s, l, dd = ora.get()
+            s_b.append(s); l_b.append(l); d_b.append(dd); g_b.append(B[:, idx].T @ B[:, idx])
+        sig.append(s_b); lvl.append(l_b); dlt.append(d_b); blk.append(g_b)
+    print(tag, "oracle sketches", round(time.time() - t0, 1), "s", flush=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", tag + ".npz"), meta=np.array([W, d, ell, seed, n_lanes] + list(steps)),
+                        input_digest=np.array(dig), R=np.array(R), levels=np.array(ora.L), sigma=np.array(sig), level=np.array(lvl),
+                        delta=np.array(dlt), gram_idx=idx, gram_block=np.array(blk))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]  # optional: tags to (re)generate
     cases = [
@@ -92,5 +119,9 @@ if __name__ == "__main__":
     for c in cases:
         if not only or c[0] in only:
             case(*c)
+    if not only or "swfd_headline_lanes" in only:
+        case_headline_lanes("swfd_headline_lanes", 10000, 1024, 128, 3, (640, 512))
+    if not only or "swfd_c3shape" in only:
+        case_sketch_checks("swfd_c3shape", 10000, 4096, 256, (640,))
     if not only or "swfd_c3orders" in only:
         case_sketch_checks("swfd_c3orders", 1024, 4096, 256, (700, 324, 1, 999, 476))

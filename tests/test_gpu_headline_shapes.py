@@ -49,27 +49,26 @@ def test_swfd_config3_orders_past_two_epoch_ends():
 
 def test_swfd_at_config3_shape_matches_oracle():
     """N = 10,000, d = 4096, l = 256 (BASELINE config 3): 640 rows = two full rotations + a ragged tail, then get():
-    singular values of the sketch against the CPU specification, 1e-8 sigma_1 (the north star asks 1e-4 relative).
+    singular values, level, final shrink and a sampled block of the covariance against the CPU specification
+    (tests/golden/swfd_c3shape.npz, make_swfd_fixtures.py), 1e-8 sigma_1 (the north star asks 1e-4 relative).
     Device == specification, not reference (parity unpinned)."""
     from mused_amd import synth
     from mused_amd.swfd import SeqBasedSWFD
-    from oracle.swfd_oracle import SeqBasedSWFD as OraSWFD
 
-    N, d, ell, rows = 10000, 4096, 256, 640
-    X, _ = synth.stream_window("blob", 0, rows, d, 0)
-    X = X.astype(np.float64)
-    R = float((X ** 2).sum(1).max())
-    ora = OraSWFD(N=N, R=R, d=d, sketch_dim=ell)
-    ora.fit(X)
-    Bo, so, lo, do = ora.get()
-    dev = SeqBasedSWFD(N=N, R=R, d=d, sketch_dim=ell)
-    dev.fit(torch.from_numpy(X).cuda())
+    g = load_golden("swfd_c3shape")
+    N, d, ell, seed = (int(x) for x in g["meta"][:4])
+    rows = int(g["meta"][4])
+    X, _ = synth.stream_window("blob", 0, rows, d, seed)
+    assert synth.array_digest(X) == str(g["input_digest"])
+    dev = SeqBasedSWFD(N=N, R=float(g["R"]), d=d, sketch_dim=ell)
+    dev.fit(torch.from_numpy(X.astype(np.float64)).cuda())
     Bd, sd, ld, dd = dev.get()
     dev.close()
-    assert ld == lo
+    so, idx = g["sigma"][0], g["gram_idx"]
+    assert ld == int(g["level"][0])
     np.testing.assert_allclose(sd, so, rtol=0, atol=1e-8 * so[0])
-    np.testing.assert_allclose(dd, do, rtol=1e-9, atol=1e-9 * so[0] ** 2)
-    np.testing.assert_allclose(Bd.T @ Bd, Bo.T @ Bo, rtol=0, atol=1e-8 * so[0] ** 2)
+    np.testing.assert_allclose(dd, float(g["delta"][0]), rtol=1e-9, atol=1e-9 * so[0] ** 2)
+    np.testing.assert_allclose(Bd[:, idx].T @ Bd[:, idx], g["gram_block"][0], rtol=0, atol=1e-8 * so[0] ** 2)
 
 
 @pytest.mark.parametrize("tag", ["swfdmc_w10k_m1", "swfdmc_w10k_m2", "swfdmc_w10k_m1_3win"])

@@ -489,37 +489,40 @@ def test_full_size_window_matches_reference_golden(name):
 
 def test_headline_shape_swfd_lanes_match_oracle_and_single_sketches():
     """The configuration bench.py times -- N = 10,000, d = 1024, l = 128, several lanes advanced in lock-step
-    with input-block pre-rotation and duplicate-level skipping on (the defaults) -- against oracle/swfd_oracle.py
-    (sigma, level, covariance) and, bit for bit, against single-lane handles, over the first 1,152 rows
-    (9 rotations of all 28 sketches per lane) of three different windows of the benchmark stream."""
+    with duplicate-level skipping on (the default) -- against oracle/swfd_oracle.py (sigma, level, final shrink, a sampled block
+    of the covariance: tests/golden/swfd_headline_lanes.npz, written by make_swfd_fixtures.py from the specification -- parity
+    unpinned) and, bit for bit, against single-lane handles, over the first 1,152 rows (9 rotations of all 28 sketches per
+    lane) of three different windows of the benchmark stream."""
     from mused_amd import synth
     from mused_amd.swfd import SeqBasedSWFD as Dev
-    from oracle.swfd_oracle import SeqBasedSWFD as Ora
 
-    W, d, ell, B, rows = 10000, 1024, 128, 3, 1152
-    Xs = [synth.stream_window("blob", t, W, d, 0)[0][:rows] for t in range(B)]
-    R = float((synth.stream_window("blob", 0, W, d, 0)[0].astype(np.float64) ** 2).sum(1).max())
+    g = load_golden("swfd_headline_lanes")
+    W, d, ell, seed, B = (int(x) for x in g["meta"][:5])
+    steps = [int(x) for x in g["meta"][5:]]
+    rows = sum(steps)
+    Xs = [synth.stream_window("blob", t, W, d, seed)[0][:rows] for t in range(B)]
+    assert [synth.array_digest(x) for x in Xs] == [str(x) for x in g["input_digest"]]
+    R = float(g["R"])
     lanes = Dev(N=W, R=R, d=d, sketch_dim=ell, lanes=B)
     singles = [Dev(N=W, R=R, d=d, sketch_dim=ell) for _ in range(B)]
-    oras = [Ora(N=W, R=R, d=d, sketch_dim=ell) for _ in range(B)]
-    assert lanes.L == oras[0].L == 14
+    assert lanes.L == int(g["levels"]) == 14
     X = torch.from_numpy(np.stack(Xs)).cuda()
+    idx = g["gram_idx"]
     t = 0
-    for step in (640, 512):  # 5 whole blocks (pre-rotated as one batch), then 4
+    for i, step in enumerate(steps):  # 5 whole blocks, then 4
         lanes.fit_lanes(X[:, t : t + step])
         for b in range(B):
             singles[b].fit(X[b, t : t + step])
-            oras[b].fit(Xs[b][t : t + step])
         t += step
         Bl, sl, ll, dl = lanes.get()
         for b in range(B):
             Bs, ss, ls, ds = singles[b].get()
             assert int(ll[b]) == ls and np.array_equal(Bl[b], Bs) and np.array_equal(sl[b], ss) and dl[b] == ds
-            Bo, so, lo, do = oras[b].get()
-            assert ls == lo
+            so = g["sigma"][b][i]
+            assert ls == int(g["level"][b][i])
             np.testing.assert_allclose(ss, so, rtol=0, atol=1e-8 * so[0])  # north star: 1e-4 rel
-            np.testing.assert_allclose(Bs.T @ Bs, Bo.T @ Bo, rtol=0, atol=1e-8 * so[0] ** 2)
-            assert abs(ds - do) <= 1e-8 * so[0] ** 2
+            np.testing.assert_allclose(Bs[:, idx].T @ Bs[:, idx], g["gram_block"][b][i], rtol=0, atol=1e-8 * so[0] ** 2)
+            assert abs(ds - float(g["delta"][b][i])) <= 1e-8 * so[0] ** 2
     lanes.close()
     for sk in singles:
         sk.close()
