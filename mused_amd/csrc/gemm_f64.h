@@ -39,6 +39,8 @@ struct GemmArgs {
   int M, N, K;
   int kchunk;  // split-K: batch index z covers k in [z*kchunk, min(K,(z+1)*kchunk)) when splitk != 0
   int splitk;
+  int bsplit;  // batched split-K: blockIdx.z = batch entry * bsplit + split; the split covers k in [split * kchunk, ...), the epilogue
+               // sees z = blockIdx.z (partial results, summed in split order by gemm_batched_splitk_reduce)
   int tiles_m, tiles_n;
   const int* rep;  // optional (batched launches): batch entry z is computed only if rep[z] == z
   int sym;  // C = A A^T (A == B, M == N) with a symmetric epilogue: only tiles on or above the diagonal are computed,
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
   extern __shared__ __attribute__((aligned(16))) double smem[];
 
   const int z = blockIdx.z;
-  if (g.rep && g.rep[z] != z) return;  // a duplicate of entry rep[z]: its consumer reads that one
+  const int zb = g.bsplit ? z / g.bsplit : z;  // batch entry
+  if (g.rep && g.rep[zb] != zb) return;  // a duplicate of entry rep[zb]: its consumer reads that one
   int tm, tn;
   if (g.sym) {
     // C = A A^T with a symmetric epilogue: the grid holds the tiles on or above the diagonal only, row-major over
@@ -293,8 +296,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f64_kernel(GemmArgs g, E
     k_lo = z * g.kchunk;
     k_hi = min(g.K, k_lo + g.kchunk);
   } else {
-    A += (long)z * g.strideA;
-    B += (long)z * g.strideB;
+    A += (long)zb * g.strideA;
+    B += (long)zb * g.strideB;
+    if (g.bsplit) {
+      k_lo = (z - zb * g.bsplit) * g.kchunk;
+      k_hi = min(g.K, k_lo + g.kchunk);
+    }
   }
 
   const int lane = threadIdx.x & 63;

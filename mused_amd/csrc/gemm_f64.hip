@@ -69,6 +69,48 @@ __global__ void splitk_reduce_kernel(const double* __restrict__ partial, int nsp
   out[i] = s;
 }
 
+// Batched split-K: partial[(z * nsplit + sp)] (M x N each, ld = N) = opA(A[z]) opB(B[z]) over k in [sp * kchunk, (sp + 1) * kchunk);
+// entries with rep[z] != z are skipped.  Sum with gemm_batched_splitk_reduce (fixed split order: results do not depend on the
+// batch).  For products whose K loop is long and whose tiles do not fill the GPU (sketch Gram matrices at d = 10,000).
+int gemm_f64_batched_splitk(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb, long strideB,
+                            double* partial, int M, int N, int K, int batch, int kchunk, int nsplit, hipStream_t stream,
+                            const int* rep) {
+  MUSED_REQUIRE(kchunk % GEMM_BK == 0 && nsplit >= 1 && (long)kchunk * nsplit >= K,
+                "gemm_f64_batched_splitk: bad kchunk %d x %d for K=%d", kchunk, nsplit, K);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.strideA = strideA; g.strideB = strideB;
+  g.M = M; g.N = N; g.K = K; g.splitk = 0; g.kchunk = kchunk; g.bsplit = nsplit;
+  g.rep = rep;
+  g.sym = (A == B && a_kc == b_kc && lda == ldb && strideA == strideB && M == N) ? 1 : 0;
+  EpiStore epi{partial, (long)N, (long)M * N, 1.0};
+  const bool vec = vec_ok<double>(A, lda, strideA) && vec_ok<double>(B, ldb, strideB);
+  if (a_kc && b_kc) return gemm_f64_launch_t<double, double, true, true>(g, batch * nsplit, epi, vec, stream);
+  if (a_kc && !b_kc) return gemm_f64_launch_t<double, double, true, false>(g, batch * nsplit, epi, vec, stream);
+  if (!a_kc && b_kc) return gemm_f64_launch_t<double, double, false, true>(g, batch * nsplit, epi, vec, stream);
+  return gemm_f64_launch_t<double, double, false, false>(g, batch * nsplit, epi, vec, stream);
+}
+
+__global__ void batched_splitk_reduce_kernel(const double* __restrict__ partial, int nsplit, long count, double* __restrict__ out,
+                                             const int* __restrict__ rep) {
+  const int z = blockIdx.y;
+  if (rep && rep[z] != z) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double* p = partial + (long)z * nsplit * count + i;
+  double s = 0.0;
+  for (int sp = 0; sp < nsplit; ++sp) s += p[(long)sp * count];  // fixed order: reproducible
+  out[(long)z * count + i] = s;
+}
+
+int gemm_batched_splitk_reduce(const double* partial, int nsplit, long count, double* out, int batch, const int* rep,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(batched_splitk_reduce_kernel, dim3(cdiv(count, 256), batch), dim3(256), 0, stream, partial, nsplit, count, out,
+                     rep);
+  MUSED_LAUNCH_CHECK();
+  return MUSED_OK;
+}
+
 int gemm_splitk_reduce(const double* partial, int nsplit, long count, double* out, hipStream_t stream) {
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(count, 256)), dim3(256), 0, stream, partial, nsplit, count,
                      out);

@@ -29,6 +29,12 @@ int gemm_f64(bool a_kc, bool b_kc, const double* A, long lda, long strideA, cons
              hipStream_t stream, const int* rep = nullptr);
 // rep (device, batch ints, optional): entry z is computed only when rep[z] == z (duplicates are skipped)
 
+// batched split-K (see gemm_f64.hip): partial results per (entry, split), then the fixed-order sum
+int gemm_f64_batched_splitk(bool a_kc, bool b_kc, const double* A, long lda, long strideA, const double* B, long ldb, long strideB,
+                            double* partial, int M, int N, int K, int batch, int kchunk, int nsplit, hipStream_t stream,
+                            const int* rep = nullptr);
+int gemm_batched_splitk_reduce(const double* partial, int nsplit, long count, double* out, int batch, const int* rep,
+                               hipStream_t stream);
 // Sets the dynamic-LDS attribute of every plain GEMM instantiation (call before stream capture).
 int gemm_f64_prepare_all();
 

@@ -42,6 +42,8 @@ struct Swfd {
   double* theta;       // S
   // rotation workspace
   double *T, *Wc, *evals, *U;
+  int gram_split;   // > 1: the buffers' Gram matrices by a batched split-K product (long rows: the K loop of a tile is the latency
+  double* gpart;    //      of the rotation and the tiles of a launch do not fill the GPU) -- S x gram_split x n2 x n2 partial sums
   int* plan;      // S x ell x 2  {kind (0 none, 1 keep, 2 dump), position}
   int* keep_src;  // S x ell      buffer position -> row of T
   long long* now_dev;
@@ -321,8 +323,14 @@ static int swfd_rotate_all(Swfd* h, hipStream_t st) {
                        (long long)h->i);
   else
     hipLaunchKernelGGL(swfd_set_now_kernel, dim3(1), dim3(1), 0, st, h->now_dev, (long long)h->i);
-  if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
-                     (long)n2 * n2, n2, n2, d, S, 1.0, st, h->rep)))
+  if (h->gram_split > 1) {
+    const int kchunk = ((d + h->gram_split - 1) / h->gram_split + 15) / 16 * 16;
+    if ((rc = gemm_f64_batched_splitk(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, h->gpart, n2, n2, d, S, kchunk,
+                                      h->gram_split, st, h->rep)))
+      return rc;
+    if ((rc = gemm_batched_splitk_reduce(h->gpart, h->gram_split, (long)n2 * n2, eig_plan_input(h->eig), S, h->rep, st))) return rc;
+  } else if ((rc = gemm_f64(true, true, h->buf, d, (long)n2 * d, h->buf, d, (long)n2 * d, eig_plan_input(h->eig), n2,
+                            (long)n2 * n2, n2, n2, d, S, 1.0, st, h->rep)))
     return rc;
   const double *ecols = nullptr, *elam = nullptr;
   int eld = 0;
@@ -707,6 +715,15 @@ static int swfd_create_impl(Swfd* h, long N, double R, int d, int ell, int sweep
   ALLOC(h->theta, 8 * S);
   ALLOC(h->T, 8 * S * l * dd); ALLOC(h->Wc, 8 * S * l * n2); ALLOC(h->evals, 8 * S * n2); ALLOC(h->U, 8 * S * n2 * n2);
   ALLOC(h->plan, 4 * S * l * 2); ALLOC(h->keep_src, 4 * S * l); ALLOC(h->now_dev, 8);
+  {
+    // rows of 8,192 entries and more (the SWFDMC wiring: d = window size): eight K-slices per tile (measured at d = 10,000, 12 lanes:
+    // 181 -> 186 / 190 k rows/s with 4 / 8 slices, 185 k with 16).  Decided by d alone -- never by the batch: lock-step lanes and
+    // single sketches must agree bit for bit.  MUSED_SWFD_GRAM_SPLIT=n overrides (1: off).
+    const char* gs = getenv("MUSED_SWFD_GRAM_SPLIT");
+    h->gram_split = gs ? atoi(gs) : (d >= 8192 ? 8 : 1);
+    if (h->gram_split < 1 || h->gram_split > 16) h->gram_split = 1;
+    if (h->gram_split > 1) ALLOC(h->gpart, 8 * S * (size_t)h->gram_split * n2 * n2);
+  }
   const size_t Bn = lanes;
   ALLOC(h->stack, 8 * Bn * n4 * dd); ALLOC(h->evals_q, 8 * Bn * n4); ALLOC(h->Uq, 8 * Bn * n4 * n4);
   ALLOC(h->Wq, 8 * Bn * l * n4); ALLOC(h->Bout, 8 * Bn * l * dd); ALLOC(h->sig_out, 8 * Bn * l);
@@ -762,7 +779,7 @@ int mused_swfd_destroy(void* handle) {
   if (h->eigp) eig_plan_destroy(h->eigp);
   void* bufs[] = {h->buf, h->queue, h->qt, h->meta, h->dropped, h->theta, h->T, h->Wc, h->evals, h->U, h->plan,
                   h->keep_src, h->now_dev, h->stack, h->evals_q, h->Uq, h->Wq, h->Bout, h->sig_out, h->qinfo, h->qsel,
-                  h->rep, h->pre_in, h->pre_out, h->pre_gram, h->status};
+                  h->rep, h->pre_in, h->pre_out, h->pre_gram, h->status, h->gpart};
   for (void* b : bufs) (void)hipFree(b);
   if (h->status_host) (void)hipHostFree(h->status_host);
   delete h;
